@@ -1,0 +1,217 @@
+/*
+ * rj.h — C-ABI of the MI355X radix-join executor (librj.so).
+ *
+ * This is the drop-in boundary for the reference's hot path: everything the
+ * reference does inside
+ *
+ *     namespace Contest { void* build_context(); void destroy_context(void*);
+ *                         ColumnarTable execute(const Plan&, void*); }
+ *     (reference include/plan.h:337-344, definitions src/execute.cpp:316-330)
+ *
+ * is reachable through the plain-C entry points below.  Signatures carry only
+ * plain pointers and sizes (no C++/torch types).  The C++ shim that sits
+ * between `Contest::execute` and this ABI is radix-join_amd/host/contest_execute.cpp;
+ * the binding a reference maintainer would add is shown in INTEGRATION.md.
+ *
+ * All functions returning `int` return RJ_OK (0) on success and a non-zero
+ * rj_status on failure; rj_last_error() then holds a message.  This mirrors
+ * the reference's error behaviour (C++ exceptions derived from std::exception,
+ * src/execute.cpp:280, build_table.cpp:335) — the shim rethrows
+ * std::runtime_error(rj_last_error()).
+ */
+#ifndef RJ_H_
+#define RJ_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RJ_PAGE_SIZE 8192u /* reference include/plan.h:54 (PAGE_SIZE) */
+
+/* DataType — values fixed by reference include/attribute.h:8-13 */
+typedef enum rj_dtype {
+    RJ_INT32   = 0,
+    RJ_INT64   = 1,
+    RJ_FP64    = 2,
+    RJ_VARCHAR = 3
+} rj_dtype;
+
+typedef enum rj_status {
+    RJ_OK            = 0,
+    RJ_ERR_ARG       = 1, /* malformed plan / bad argument                    */
+    RJ_ERR_DEVICE    = 2, /* HIP runtime error                                */
+    RJ_ERR_NOMEM     = 3, /* device or host allocation failed                 */
+    RJ_ERR_DATA      = 4, /* pages inconsistent with num_rows ("row_idx",
+                             reference build_table.cpp:334-336)               */
+    RJ_ERR_UNSUPPORTED = 5, /* e.g. VARCHAR join key (never occurs in JOB,
+                             reference ANNOUNCEMENTS.md:11)                   */
+    RJ_ERR_NO_GPU    = 6  /* no usable HIP device: the product path has no
+                             CPU fallback and fails loudly                    */
+} rj_status;
+
+/* ------------------------------------------------------------------ plan --
+ * POD flattening of reference `Plan` (include/plan.h:32-52,112-149).
+ * nodes[i].kind: RJ_NODE_SCAN ↔ ScanNode{base_table_id},
+ *                RJ_NODE_JOIN ↔ JoinNode{build_left,left,right,left_attr,right_attr}.
+ * out_idx/out_type ↔ PlanNode::output_attrs (vector<tuple<size_t,DataType>>):
+ *   scan: index into the base table's columns;
+ *   join: index into concat(left child outputs, right child outputs)
+ *         (reference README.md:55, src/execute.cpp:236-242).                 */
+typedef enum rj_node_kind { RJ_NODE_SCAN = 0, RJ_NODE_JOIN = 1 } rj_node_kind;
+
+typedef struct rj_node {
+    int32_t         kind;          /* rj_node_kind                            */
+    int32_t         build_left;    /* JoinNode::build_left (0/1)              */
+    uint64_t        base_table_id; /* ScanNode::base_table_id                 */
+    uint64_t        left, right;   /* JoinNode child node indices             */
+    uint64_t        left_attr, right_attr;
+    uint64_t        n_out;
+    const uint64_t* out_idx;       /* [n_out] */
+    const int32_t*  out_type;      /* [n_out] rj_dtype */
+} rj_node;
+
+/* One Column (include/plan.h:60-100): `pages[i]` points at an 8192-byte Page. */
+typedef struct rj_column {
+    int32_t            type;    /* rj_dtype */
+    uint64_t           n_pages;
+    const void* const* pages;   /* [n_pages] host pointers, each RJ_PAGE_SIZE bytes */
+} rj_column;
+
+/* One ColumnarTable (include/plan.h:102-105). */
+typedef struct rj_input {
+    uint64_t         num_rows;
+    uint64_t         n_cols;
+    const rj_column* cols;
+} rj_input;
+
+typedef struct rj_plan {
+    uint64_t        n_nodes;
+    const rj_node*  nodes;
+    uint64_t        n_inputs;
+    const rj_input* inputs; /* may be NULL for rj_execute_resident */
+    uint64_t        root;
+} rj_plan;
+
+/* --------------------------------------------------------------- context --
+ * rj_context_create ↔ Contest::build_context() (src/execute.cpp:326-328)
+ * rj_context_destroy ↔ Contest::destroy_context() (src/execute.cpp:330)      */
+typedef struct rj_context rj_context;
+
+typedef struct rj_config {
+    int32_t  device;      /* HIP device ordinal; -1 = current device          */
+    int32_t  profile;     /* !=0: bracket every kernel with HIP events        */
+    void*    stream;      /* hipStream_t to launch on; NULL = library-owned   */
+    int32_t  radix_bits;  /* total radix bits; 0 = auto from build cardinality */
+    int32_t  reserved0;
+    uint64_t reserved1;
+} rj_config;
+
+int         rj_context_create(rj_context** out, const rj_config* cfg /* may be NULL */);
+void        rj_context_destroy(rj_context* ctx);
+const char* rj_last_error(const rj_context* ctx); /* ctx may be NULL: last create error */
+int         rj_abi_version(void);
+
+/* ---------------------------------------------------------------- tables --
+ * A device-resident ColumnarTable: the Page images of every fixed-width
+ * column live contiguously in HBM; VARCHAR pages stay on the host (they are
+ * only ever gathered at the root, never joined on).                          */
+typedef struct rj_table rj_table;
+
+/* Copy host pages into HBM (pinned staging + async H2D).                     */
+int  rj_table_upload(rj_context* ctx, const rj_input* host, rj_table** out);
+
+/* Adopt page images that already sit in HBM: dev_pages[c] is a device pointer
+ * to n_pages[c] contiguous 8192-byte pages of column c (NULL for VARCHAR
+ * columns, which then must not be referenced).  No copy; caller keeps
+ * ownership and must keep the memory alive while the table is in use.        */
+int  rj_table_adopt_device(rj_context* ctx, uint64_t num_rows, uint64_t n_cols,
+                           const int32_t* col_type, const void* const* dev_pages,
+                           const uint64_t* n_pages, rj_table** out);
+void rj_table_release(rj_context* ctx, rj_table* t);
+
+/* --------------------------------------------------------------- execute --
+ * rj_execute ↔ Contest::execute(const Plan&, void*) (src/execute.cpp:316-324):
+ *   inputs are the host pages in plan->inputs; the result pages are produced
+ *   on the device and fetched with rj_result_copy_pages.
+ * rj_execute_resident: same plan semantics, inputs already in HBM
+ *   (plan->inputs ignored; tables[i] ↔ plan.inputs[i]).  With
+ *   RJ_EXEC_KEEP_ON_DEVICE the fixed-width result pages stay in HBM.         */
+typedef struct rj_result rj_result;
+
+enum { RJ_EXEC_KEEP_ON_DEVICE = 1 };
+
+int rj_execute(rj_context* ctx, const rj_plan* plan, rj_result** out);
+int rj_execute_resident(rj_context* ctx, const rj_plan* plan, rj_table* const* tables,
+                        uint64_t n_tables, int32_t flags, rj_result** out);
+
+uint64_t rj_result_num_rows(const rj_result* r);
+uint64_t rj_result_num_cols(const rj_result* r);
+int32_t  rj_result_col_type(const rj_result* r, uint64_t col);
+uint64_t rj_result_col_pages(const rj_result* r, uint64_t col);
+/* Copy column `col` into caller-allocated pages (dst[i] = 8192-byte block,
+ * e.g. `new Page` so that Column::~Column, plan.h:95-99, can delete them).   */
+int      rj_result_copy_pages(rj_result* r, uint64_t col, void* const* dst, uint64_t n_dst);
+/* Device pointer to the contiguous page images of a fixed-width column
+ * (valid until rj_result_free); NULL for VARCHAR columns.                    */
+const void* rj_result_device_pages(const rj_result* r, uint64_t col);
+void     rj_result_free(rj_result* r);
+
+/* ------------------------------------------------------- sharded (multi-GPU)
+ * One process per GPU.  The join shards by hash of the key: rank r owns the
+ * tuples whose hash digit == r.  Stage A runs locally on every rank, the
+ * caller exchanges the per-destination slices with one all-to-all (RCCL via
+ * torch.distributed in bench.py / pyrj.dist), stage B joins what arrived.
+ * Tuples are SoA: `key` (int32) plus `carry` (one 32-bit word per tuple, the
+ * payload or a row id).                                                      */
+typedef struct rj_tuples {
+    uint64_t n;
+    void*    key;    /* device, n * 4 bytes  */
+    void*    carry;  /* device, n * 4 bytes  */
+} rj_tuples;
+
+/* Stage A: decode (key_col, carry_col) of a resident table and partition the
+ * non-NULL-key tuples by destination rank.  On return out->key/carry hold the
+ * tuples grouped by rank (rank 0 first) and counts[r] the tuples for rank r.
+ * Buffers belong to the context; free with rj_tuples_free.                   */
+int  rj_shard_partition(rj_context* ctx, const rj_table* t, uint64_t key_col,
+                        uint64_t carry_col, uint32_t n_ranks, rj_tuples* out,
+                        uint64_t* counts /* [n_ranks] */);
+void rj_tuples_free(rj_context* ctx, rj_tuples* t);
+
+/* Stage B: inner equi-join of two tuple sets resident in HBM (caller-owned
+ * device pointers).  Output columns: key, build carry, probe carry — i.e. the
+ * plan Join(build_left=true, out={0,1,3}) over Scan{key,payload} children.
+ * skip_rank_bits = log2(n_ranks) hash bits already consumed by stage A.      */
+int  rj_join_tuples(rj_context* ctx, const rj_tuples* build, const rj_tuples* probe,
+                    uint32_t skip_rank_bits, int32_t flags, rj_result** out);
+
+/* -------------------------------------------------------------- profiling --
+ * With rj_config.profile != 0 every kernel launch is bracketed by HIP events
+ * on the launch stream.  rj_profile_read drains them (synchronises).         */
+typedef struct rj_kernel_stat {
+    char     name[48];
+    uint64_t launches;
+    double   total_ms;
+} rj_kernel_stat;
+
+int  rj_profile_read(rj_context* ctx, rj_kernel_stat* out, uint64_t cap, uint64_t* n);
+void rj_profile_reset(rj_context* ctx);
+
+/* Device properties the host side reports next to its numbers. */
+typedef struct rj_device_info {
+    char     name[128];
+    char     arch[64];
+    int32_t  compute_units;
+    int32_t  wavefront;
+    uint64_t hbm_bytes;
+    uint64_t lds_per_cu;
+} rj_device_info;
+int rj_device_query(rj_context* ctx, rj_device_info* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RJ_H_ */
