@@ -170,16 +170,20 @@ typedef struct rj_tuples {
     uint64_t n;
     void*    key;    /* device, n * 4 bytes  */
     void*    carry;  /* device, n * 4 bytes  */
+    uint32_t hashed; /* !=0: `key` holds the library's bijective hash image of the
+                        keys (what stage A emits; stage B un-hashes on output)  */
+    uint32_t reserved;
 } rj_tuples;
 
 /* Stage A: decode (key_col, carry_col) of a resident table and partition the
- * non-NULL-key tuples by destination rank.  On return out->key/carry hold the
- * tuples grouped by rank (rank 0 first) and counts[r] the tuples for rank r.
- * Buffers belong to the context; free with rj_tuples_free.                   */
+ * non-NULL-key tuples by destination rank.  The caller provides out->key and
+ * out->carry (device buffers with room for the table's num_rows tuples, e.g.
+ * torch tensors that then go straight into the all-to-all).  On return they
+ * hold the tuples grouped by rank (rank 0 first), out->n the tuple count,
+ * out->hashed = 1 and counts[r] the tuples destined for rank r.              */
 int  rj_shard_partition(rj_context* ctx, const rj_table* t, uint64_t key_col,
                         uint64_t carry_col, uint32_t n_ranks, rj_tuples* out,
                         uint64_t* counts /* [n_ranks] */);
-void rj_tuples_free(rj_context* ctx, rj_tuples* t);
 
 /* Stage B: inner equi-join of two tuple sets resident in HBM (caller-owned
  * device pointers).  Output columns: key, build carry, probe carry — i.e. the

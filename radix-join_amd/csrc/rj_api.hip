@@ -1,0 +1,233 @@
+// rj_api.hip — the extern "C" boundary (include/rj.h).  Every entry point turns
+// C++ exceptions into status codes + rj_last_error().
+#include <mutex>
+
+#include "rj_internal.hpp"
+
+using namespace rj;
+
+static std::mutex  g_err_mu;
+static std::string g_create_error;
+
+template <class F>
+static int guarded(rj_context* ctx, F&& f) {
+    try {
+        f();
+        return RJ_OK;
+    } catch (const rj::Error& e) {
+        if (ctx) ctx->last_error = e.what();
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        if (ctx) ctx->last_error = "host allocation failed";
+        return RJ_ERR_NOMEM;
+    } catch (const std::exception& e) {
+        if (ctx) ctx->last_error = e.what();
+        return RJ_ERR_DEVICE;
+    }
+}
+
+extern "C" {
+
+int rj_abi_version(void) { return 1; }
+
+int rj_context_create(rj_context** out, const rj_config* cfg) {
+    if (!out) return RJ_ERR_ARG;
+    *out = nullptr;
+    int         code = RJ_OK;
+    std::string msg;
+    try {
+        int n_dev = 0;
+        if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) {
+            (void)hipGetLastError();
+            throw rj::Error(RJ_ERR_NO_GPU,
+                            "no HIP device: librj has no CPU fallback (the GPU path is the product)");
+        }
+        std::unique_ptr<rj_context> c(new rj_context());
+        int dev = cfg ? cfg->device : -1;
+        if (dev < 0) RJ_HIP(hipGetDevice(&dev));
+        if (dev >= n_dev) throw rj::Error(RJ_ERR_ARG, "device ordinal out of range");
+        RJ_HIP(hipSetDevice(dev));
+        c->device = dev;
+        if (cfg && cfg->stream) {
+            c->stream = static_cast<hipStream_t>(cfg->stream);
+        } else {
+            RJ_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+            c->own_stream = true;
+        }
+        c->prof.on = cfg && cfg->profile;
+        c->prof.stream = c->stream;
+        c->radix_bits_override = cfg ? cfg->radix_bits : 0;
+        *out = c.release();
+    } catch (const rj::Error& e) {
+        code = e.code;
+        msg = e.what();
+    } catch (const std::exception& e) {
+        code = RJ_ERR_DEVICE;
+        msg = e.what();
+    }
+    if (code != RJ_OK) {
+        std::lock_guard<std::mutex> g(g_err_mu);
+        g_create_error = msg;
+    }
+    return code;
+}
+
+void rj_context_destroy(rj_context* ctx) {
+    if (!ctx) return;
+    delete ctx;
+}
+
+const char* rj_last_error(const rj_context* ctx) {
+    if (ctx) return ctx->last_error.c_str();
+    std::lock_guard<std::mutex> g(g_err_mu);
+    return g_create_error.c_str();
+}
+
+int rj_table_upload(rj_context* ctx, const rj_input* host, rj_table** out) {
+    if (!ctx || !out) return RJ_ERR_ARG;
+    *out = nullptr;
+    return guarded(ctx, [&] {
+        RJ_HIP(hipSetDevice(ctx->device));
+        *out = static_cast<rj_table*>(table_upload(ctx, host));
+    });
+}
+
+int rj_table_adopt_device(rj_context* ctx, uint64_t num_rows, uint64_t n_cols,
+                          const int32_t* col_type, const void* const* dev_pages,
+                          const uint64_t* n_pages, rj_table** out) {
+    if (!ctx || !out || (n_cols && (!col_type || !dev_pages || !n_pages))) return RJ_ERR_ARG;
+    *out = nullptr;
+    return guarded(ctx, [&] {
+        RJ_HIP(hipSetDevice(ctx->device));
+        *out = static_cast<rj_table*>(
+            table_adopt(ctx, num_rows, n_cols, col_type, dev_pages, n_pages));
+    });
+}
+
+void rj_table_release(rj_context* ctx, rj_table* t) {
+    (void)ctx;
+    delete t;
+}
+
+int rj_execute_resident(rj_context* ctx, const rj_plan* plan, rj_table* const* tables,
+                        uint64_t n_tables, int32_t flags, rj_result** out) {
+    if (!ctx || !plan || !out) return RJ_ERR_ARG;
+    *out = nullptr;
+    return guarded(ctx, [&] {
+        RJ_HIP(hipSetDevice(ctx->device));
+        std::vector<Table*> ts(n_tables);
+        for (uint64_t i = 0; i < n_tables; ++i) {
+            if (!tables[i]) throw rj::Error(RJ_ERR_ARG, "null table");
+            ts[i] = tables[i];
+        }
+        *out = static_cast<rj_result*>(execute_plan(ctx, plan, ts.data(), n_tables, flags));
+    });
+}
+
+int rj_execute(rj_context* ctx, const rj_plan* plan, rj_result** out) {
+    if (!ctx || !plan || !out) return RJ_ERR_ARG;
+    *out = nullptr;
+    return guarded(ctx, [&] {
+        RJ_HIP(hipSetDevice(ctx->device));
+        if (plan->n_inputs && !plan->inputs) throw rj::Error(RJ_ERR_ARG, "plan has no inputs");
+        // upload only the inputs some ScanNode reads
+        std::vector<bool> used(plan->n_inputs, false);
+        for (uint64_t i = 0; i < plan->n_nodes; ++i)
+            if (plan->nodes[i].kind == RJ_NODE_SCAN) {
+                if (plan->nodes[i].base_table_id >= plan->n_inputs)
+                    throw rj::Error(RJ_ERR_ARG, "scan: bad base_table_id");
+                used[plan->nodes[i].base_table_id] = true;
+            }
+        std::vector<std::unique_ptr<Table>> owned(plan->n_inputs);
+        std::vector<Table*>                 ts(plan->n_inputs, nullptr);
+        rj_input                            none{};
+        for (uint64_t i = 0; i < plan->n_inputs; ++i) {
+            owned[i].reset(table_upload(ctx, used[i] ? &plan->inputs[i] : &none));
+            ts[i] = owned[i].get();
+        }
+        *out = static_cast<rj_result*>(execute_plan(ctx, plan, ts.data(), plan->n_inputs, 0));
+    });
+}
+
+uint64_t rj_result_num_rows(const rj_result* r) { return r ? r->num_rows : 0; }
+uint64_t rj_result_num_cols(const rj_result* r) { return r ? r->cols.size() : 0; }
+int32_t  rj_result_col_type(const rj_result* r, uint64_t c) {
+    return (r && c < r->cols.size()) ? r->cols[c].type : -1;
+}
+uint64_t rj_result_col_pages(const rj_result* r, uint64_t c) {
+    return (r && c < r->cols.size()) ? r->cols[c].n_pages : 0;
+}
+
+int rj_result_copy_pages(rj_result* r, uint64_t col, void* const* dst, uint64_t n_dst) {
+    if (!r) return RJ_ERR_ARG;
+    return guarded(static_cast<rj_context*>(r->ctx), [&] {
+        RJ_HIP(hipSetDevice(r->ctx->device));
+        result_copy_pages(r, col, dst, n_dst);
+    });
+}
+
+const void* rj_result_device_pages(const rj_result* r, uint64_t c) {
+    if (!r || c >= r->cols.size() || !r->cols[c].dev_pages) return nullptr;
+    return r->cols[c].dev_pages->p;
+}
+
+void rj_result_free(rj_result* r) { delete r; }
+
+int rj_shard_partition(rj_context* ctx, const rj_table* t, uint64_t key_col, uint64_t carry_col,
+                       uint32_t n_ranks, rj_tuples* out, uint64_t* counts) {
+    if (!ctx || !t || !out || !counts) return RJ_ERR_ARG;
+    return guarded(ctx, [&] {
+        RJ_HIP(hipSetDevice(ctx->device));
+        shard_partition(ctx, t, key_col, carry_col, n_ranks, out, counts);
+    });
+}
+
+int rj_join_tuples(rj_context* ctx, const rj_tuples* build, const rj_tuples* probe,
+                   uint32_t skip_rank_bits, int32_t flags, rj_result** out) {
+    if (!ctx || !build || !probe || !out) return RJ_ERR_ARG;
+    *out = nullptr;
+    return guarded(ctx, [&] {
+        RJ_HIP(hipSetDevice(ctx->device));
+        *out = static_cast<rj_result*>(join_tuples(ctx, build, probe, skip_rank_bits, flags));
+    });
+}
+
+int rj_profile_read(rj_context* ctx, rj_kernel_stat* out, uint64_t cap, uint64_t* n) {
+    if (!ctx || !n) return RJ_ERR_ARG;
+    return guarded(ctx, [&] {
+        ctx->prof.drain();
+        uint64_t k = 0;
+        for (const std::string& name : ctx->prof.order) {
+            if (k < cap && out) {
+                memset(&out[k], 0, sizeof out[k]);
+                strncpy(out[k].name, name.c_str(), sizeof(out[k].name) - 1);
+                out[k].launches = ctx->prof.totals[name].launches;
+                out[k].total_ms = ctx->prof.totals[name].ms;
+            }
+            ++k;
+        }
+        *n = k;
+    });
+}
+
+void rj_profile_reset(rj_context* ctx) {
+    if (!ctx) return;
+    (void)guarded(ctx, [&] { ctx->prof.reset(); });
+}
+
+int rj_device_query(rj_context* ctx, rj_device_info* out) {
+    if (!ctx || !out) return RJ_ERR_ARG;
+    return guarded(ctx, [&] {
+        hipDeviceProp_t p;
+        RJ_HIP(hipGetDeviceProperties(&p, ctx->device));
+        memset(out, 0, sizeof *out);
+        strncpy(out->name, p.name, sizeof(out->name) - 1);
+        strncpy(out->arch, p.gcnArchName, sizeof(out->arch) - 1);
+        out->compute_units = p.multiProcessorCount;
+        out->wavefront = p.warpSize;
+        out->hbm_bytes = p.totalGlobalMem;
+        out->lds_per_cu = p.maxSharedMemoryPerMultiProcessor;
+    });
+}
+
+}  // extern "C"

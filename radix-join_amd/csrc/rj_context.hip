@@ -1,0 +1,156 @@
+// rj_context.hip — context, HBM block cache, HIP-event profiler.
+#include "rj_internal.hpp"
+
+namespace rj {
+
+// ---------------------------------------------------------------- DevPool --
+static size_t round_size(size_t n) {
+    const size_t small = 256, big = size_t(2) << 20;
+    if (n < (size_t(1) << 20)) return (n + small - 1) / small * small;
+    return (n + big - 1) / big * big;
+}
+
+void* DevPool::alloc(size_t bytes) {
+    size_t need = round_size(bytes ? bytes : 1);
+    int    best = -1;
+    for (size_t i = 0; i < blocks_.size(); ++i) {
+        Block& b = blocks_[i];
+        if (!b.free || b.size < need) continue;
+        if (b.size > need + need / 2 + (size_t(4) << 20)) continue;  // don't burn huge blocks
+        if (best < 0 || b.size < blocks_[best].size) best = (int)i;
+    }
+    if (best >= 0) {
+        blocks_[best].free = false;
+        in_use_ += blocks_[best].size;
+        cached_ -= blocks_[best].size;
+        return blocks_[best].p;
+    }
+    void*      p = nullptr;
+    hipError_t e = hipMalloc(&p, need);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        trim();
+        e = hipMalloc(&p, need);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            throw_fmt(RJ_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", need, hipGetErrorString(e));
+        }
+    }
+    blocks_.push_back({p, need, false});
+    in_use_ += need;
+    return p;
+}
+
+void DevPool::release(void* p) {
+    if (!p) return;
+    for (Block& b : blocks_)
+        if (b.p == p && !b.free) {
+            b.free = true;
+            in_use_ -= b.size;
+            cached_ += b.size;
+            return;
+        }
+}
+
+void DevPool::trim() {
+    std::vector<Block> keep;
+    for (Block& b : blocks_) {
+        if (b.free) {
+            (void)hipFree(b.p);
+            cached_ -= b.size;
+        } else {
+            keep.push_back(b);
+        }
+    }
+    blocks_.swap(keep);
+}
+
+DevPool::~DevPool() {
+    for (Block& b : blocks_) (void)hipFree(b.p);
+}
+
+Buf::Buf(Context* c, size_t n) : ctx(c), bytes(n) { p = c->pool.alloc(n); }
+Buf::~Buf() {
+    if (ctx && p) ctx->pool.release(p);
+}
+
+// --------------------------------------------------------------- Profiler --
+hipEvent_t Profiler::get_event() {
+    if (!spare_.empty()) {
+        hipEvent_t e = spare_.back();
+        spare_.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    RJ_HIP(hipEventCreate(&e));
+    return e;
+}
+
+void Profiler::begin(const char* name) {
+    if (!on) return;
+    Rec r{name, get_event(), get_event()};
+    RJ_HIP(hipEventRecord(r.a, stream));
+    open_.push_back(r);
+}
+
+void Profiler::end() {
+    if (!on || open_.empty()) return;
+    RJ_HIP(hipEventRecord(open_.back().b, stream));
+}
+
+void Profiler::drain() {
+    if (open_.empty()) return;
+    RJ_HIP(hipStreamSynchronize(stream));
+    for (Rec& r : open_) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            auto it = totals.find(r.name);
+            if (it == totals.end()) {
+                order.push_back(r.name);
+                it = totals.emplace(r.name, Tot{}).first;
+            }
+            it->second.launches++;
+            it->second.ms += ms;
+        } else {
+            (void)hipGetLastError();
+        }
+        spare_.push_back(r.a);
+        spare_.push_back(r.b);
+    }
+    open_.clear();
+}
+
+void Profiler::reset() {
+    drain();
+    totals.clear();
+    order.clear();
+}
+
+Profiler::~Profiler() {
+    for (Rec& r : open_) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    for (hipEvent_t e : spare_) (void)hipEventDestroy(e);
+}
+
+// ---------------------------------------------------------------- Context --
+void* Context::staging(size_t bytes) {
+    if (bytes > pinned_bytes) {
+        if (pinned) (void)hipHostFree(pinned);
+        pinned = nullptr;
+        pinned_bytes = 0;
+        RJ_HIP(hipHostMalloc(&pinned, bytes, hipHostMallocDefault));
+        pinned_bytes = bytes;
+    }
+    return pinned;
+}
+
+Context::~Context() {
+    if (stream) (void)hipStreamSynchronize(stream);
+    if (pinned) (void)hipHostFree(pinned);
+    if (pinned_small) (void)hipHostFree(pinned_small);
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+}
+
+}  // namespace rj

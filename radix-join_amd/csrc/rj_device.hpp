@@ -1,0 +1,119 @@
+// rj_device.hpp — POD structs and tuning constants shared by the host executor
+// and the gfx950 kernels.  Everything here is written for MI355X only: wave64,
+// 160 KiB LDS per CU, 256 CUs in 8 XCDs.
+#pragma once
+#include <stdint.h>
+
+namespace rj {
+
+// ---- Page geometry (reference include/plan.h:54, src/build_table.cpp:488,531)
+constexpr uint32_t PAGE_BYTES = 8192;
+constexpr uint32_t ROWS32 = 1984;  // rows of a full non-NULL INT32 page
+constexpr uint32_t ROWS64 = 1007;  // rows of a full non-NULL INT64/FP64 page
+constexpr uint32_t HDR32 = 4;      // first value offset, INT32
+constexpr uint32_t HDR64 = 8;      // first value offset, INT64/FP64
+
+// ---- Columns as the kernels see them
+enum ColKind : int32_t {
+    COL_NONE  = 0,
+    COL_PAGED = 1,  // "regular" page images: every page but the last holds ROWS32/ROWS64
+                    // non-NULL values, so row r lives at page r / ROWS, slot r % ROWS
+    COL_DENSE = 2,  // flat array of 4- or 8-byte values (+ optional validity bytes)
+    COL_IOTA  = 3   // value(row) = row: the row-id column of a base table (late
+                    // materialisation of VARCHAR)
+};
+
+struct ColRef {
+    const uint8_t* ptr;
+    const uint8_t* valid;  // COL_DENSE only; nullptr = all rows valid
+    int32_t        kind;
+    int32_t        width;  // 4 or 8
+};
+
+// What travels with the key through the radix passes.
+enum CarryMode : int32_t {
+    CARRY_NONE   = 0,
+    CARRY_ROWIDX = 1,  // row index into the child relation (generic path: gather later)
+    CARRY_COLUMN = 2   // the single payload column itself (direct path: no gather)
+};
+
+struct TupleSrc {
+    ColRef   key;
+    ColRef   carry;
+    uint32_t n_rows;
+    int32_t  carry_mode;
+    int32_t  key_f64;    // FP64 key: compared by bit pattern, NaN never matches
+    int32_t  prehashed;  // key column already holds hashed keys (sharded stage B)
+};
+
+// Partitioned tuples are SoA arrays of 32-bit words:
+//   word 0            = hashed key (low 32 bits); radix digits and slot bits come from it
+//   word 1 (KW == 2)  = high 32 bits of the 64-bit hashed key
+//   following words   = carry (0, 1 or 2 words)
+constexpr int MAX_WORDS = 4;
+struct Words {
+    uint32_t* w[MAX_WORDS];
+};
+
+// ---- Radix partition pass --------------------------------------------------
+// One workgroup sorts a tile of PT_TILE tuples by digit in LDS and writes each
+// digit's run contiguously (software write-combining), see rj_kernels.hip.
+constexpr int PT_THREADS = 512;                   // 8 waves
+constexpr int PT_ITEMS   = 16;                    // tuples per thread per tile
+constexpr int PT_TILE    = PT_THREADS * PT_ITEMS; // 8192 tuples = 32 KiB per word array
+constexpr int PT_MAXF    = 512;                   // max fan-out per pass (9 bits)
+constexpr int PT_MAXBITS = 9;
+
+struct PassParams {
+    const uint32_t* seg_off;    // [nseg+1] input segments (previous pass' partitions);
+                                // nullptr = one segment [0, n)
+    const uint32_t* grp_start;  // [nseg+1] exclusive scan of groups per segment (nseg > 1)
+    uint32_t        nseg;
+    uint32_t        n;          // tuples (single-segment case)
+    uint32_t        shift;      // digit = (word0 >> shift) & (F-1)
+    uint32_t        fanout_log2;
+    uint32_t        tiles_per_group;
+    uint32_t*       group_hist; // [groups][F]   written by the histogram kernel
+    uint32_t*       hist;       // [nseg*F]      global bin totals
+    uint32_t*       cursor;     // [nseg*F]      write cursors (start = exclusive scan of hist)
+};
+
+// ---- Build/probe -------------------------------------------------------------
+constexpr int      JN_THREADS = 512;
+constexpr int      JN_SPT     = 8;                     // probe tuples per thread per sub-chunk
+constexpr int      JN_SUB     = JN_THREADS * JN_SPT;   // 4096
+constexpr int      JN_CAP     = 8192;                  // LDS table slots
+constexpr int      JN_RMAX    = JN_CAP / 2;            // build tuples per table (load <= 50 %)
+constexpr uint32_t JN_HEAVY   = 32768;                 // probe tuples per task before splitting
+constexpr uint32_t JN_TARGET_BUILD = 3072;             // mean build tuples per final partition
+
+enum StreamMode : int32_t {
+    ST_NONE    = 0,
+    ST_DENSE32 = 1,
+    ST_DENSE64 = 2,
+    ST_PAGED32 = 3,  // page images, ROWS32 per page, values from +4
+    ST_PAGED64 = 4   // page images, ROWS64 per page, values from +8
+};
+
+struct OutStream {
+    uint8_t* base;
+    int32_t  mode;
+    int32_t  pad;
+};
+
+struct JoinParams {
+    Words           R, S;
+    const uint32_t* offR;   // [NP+1]
+    const uint32_t* offS;   // [NP+1]
+    uint32_t        NP;
+    uint32_t        radix_bits;  // low bits of word 0 shared by a partition's tuples
+    OutStream       key, bc, pc; // emitted streams: key, build carry, probe carry
+    unsigned long long* out_cursor;
+    uint64_t        out_cap;     // rows that fit the stream buffers
+    const uint32_t* heavy_tasks; // [n][3] = {partition, s_begin, s_end}
+    const uint32_t* n_heavy;
+    int32_t         heavy_pass;  // 0: one workgroup per partition; 1: heavy task list
+    int32_t         pad;
+};
+
+}  // namespace rj

@@ -1,0 +1,683 @@
+// rj_exec.hip — plan executor: the host logic of Contest::execute on MI355X.
+//
+// Replaces reference src/execute.cpp:266-324 (execute, execute_impl, execute_scan,
+// execute_hash_join, hash_join_omp).  Shape: columnar + late materialisation.
+//   * A node's result ("Rel") is a set of device columns: regular page images
+//     addressed in place, dense arrays, or row-id columns standing for VARCHAR.
+//   * A JoinNode radix-partitions (hashed key, carry) tuples of both children
+//     with the same bit plan, joins co-partitions in LDS and emits up to three
+//     streams: key, build carry, probe carry.  The carry is the single payload
+//     column itself when a side needs only one (no gather afterwards), else the
+//     row index into the child, gathered per output column.
+//   * At the root the streams are written straight into Page images.
+#include <algorithm>
+#include <set>
+
+#include "rj_internal.hpp"
+
+namespace rj {
+
+namespace {
+
+struct DCol {
+    int32_t        type = RJ_INT32;  // declared DataType
+    int32_t        kind = COL_NONE;
+    int32_t        width = 4;  // bytes per value on device (VARCHAR: 4 = row id)
+    const uint8_t* ptr = nullptr;
+    const uint8_t* valid = nullptr;
+    BufP           hold, hold_valid;
+    int            vc_table = -1, vc_col = -1;  // VARCHAR provenance (base table, column)
+    const TableColumn* tcol = nullptr;          // scan passthrough
+    ColRef ref() const { return ColRef{ptr, valid, kind, width}; }
+};
+
+struct Rel {
+    uint64_t          n = 0;
+    std::vector<DCol> cols;
+};
+
+struct Parted {
+    int      NW = 0;
+    BufP     wbuf[MAX_WORDS];
+    Words    w{};
+    BufP     off;  // u32[NP+1]
+    uint32_t NP = 0;
+};
+
+struct JoinSpec {
+    bool                  build_left = true;
+    uint64_t              left_attr = 0, right_attr = 0;
+    std::vector<uint64_t> out_idx;
+    std::vector<int32_t>  out_type;
+    bool                  prehashed = false;
+    int                   forced_bits = 0;
+};
+
+uint32_t ceil_log2(uint64_t v) {
+    uint32_t b = 0;
+    while ((uint64_t(1) << b) < v) ++b;
+    return b;
+}
+
+class Exec {
+   public:
+    Exec(Context* c, const rj_plan* p, Table* const* t, uint64_t nt, int fl)
+        : ctx(c), plan(p), tables(t), n_tables(nt), flags(fl), L(c->launch()) {}
+
+    Result* run() {
+        if (!plan || plan->root >= plan->n_nodes) throw_fmt(RJ_ERR_ARG, "bad plan root");
+        std::unique_ptr<Result> res(new rj_result());
+        res->ctx = ctx;
+        const rj_node& root = plan->nodes[plan->root];
+        if (root.kind == RJ_NODE_SCAN) {
+            root_scan(root, *res);
+        } else {
+            (void)node(plan->root, res.get(), 0);
+        }
+        ctx->sync();
+        return res.release();
+    }
+
+    // rj_join_tuples: same join core over caller-provided dense tuples
+    Result* run_tuples(const rj_tuples* b, const rj_tuples* p, uint32_t /*skip_rank_bits*/) {
+        std::unique_ptr<Result> res(new rj_result());
+        res->ctx = ctx;
+        auto mk = [](const rj_tuples* t) {
+            Rel r;
+            r.n = t->n;
+            DCol k;
+            k.type = RJ_INT32;
+            k.kind = COL_DENSE;
+            k.width = 4;
+            k.ptr = static_cast<const uint8_t*>(t->key);
+            DCol c = k;
+            c.ptr = static_cast<const uint8_t*>(t->carry);
+            r.cols = {k, c};
+            return r;
+        };
+        if (b->n > 0xfffffff0ull || p->n > 0xfffffff0ull)
+            throw_fmt(RJ_ERR_UNSUPPORTED, "more than 2^32 tuples");
+        if (b->hashed != p->hashed) throw_fmt(RJ_ERR_ARG, "build/probe disagree on `hashed`");
+        Rel      lb = mk(b), rp = mk(p);
+        JoinSpec js;
+        js.build_left = true;
+        js.out_idx = {0, 1, 3};
+        js.out_type = {RJ_INT32, RJ_INT32, RJ_INT32};
+        js.prehashed = b->hashed != 0;
+        (void)join_core(lb, rp, js, res.get());
+        ctx->sync();
+        return res.release();
+    }
+
+    // rj_shard_partition: decode + hash + one pass over the TOP log2(n_ranks) hash bits
+    void run_shard(const Table* t, uint64_t key_col, uint64_t carry_col, uint32_t n_ranks,
+                   rj_tuples* out, uint64_t* counts) {
+        if (n_ranks == 0 || (n_ranks & (n_ranks - 1)) || n_ranks > PT_MAXF)
+            throw_fmt(RJ_ERR_UNSUPPORTED, "n_ranks must be a power of two <= %d", PT_MAXF);
+        if (key_col >= t->cols.size() || carry_col >= t->cols.size())
+            throw_fmt(RJ_ERR_ARG, "column out of range");
+        DCol k = table_col(t, (int)key_col), c = table_col(t, (int)carry_col);
+        if (k.type != RJ_INT32 || c.type != RJ_INT32)
+            throw_fmt(RJ_ERR_UNSUPPORTED, "sharded path carries INT32 key + INT32 payload");
+        if (c.valid) throw_fmt(RJ_ERR_UNSUPPORTED, "sharded path: payload column has NULLs");
+        TupleSrc src{};
+        src.key = k.ref();
+        src.carry = c.ref();
+        src.n_rows = (uint32_t)t->num_rows;
+        src.carry_mode = CARRY_COLUMN;
+        if (!out->key || !out->carry) throw_fmt(RJ_ERR_ARG, "rj_shard_partition: null output buffers");
+        uint32_t rb = ceil_log2(n_ranks);
+        Words    ext{};
+        ext.w[0] = static_cast<uint32_t*>(out->key);
+        ext.w[1] = static_cast<uint32_t*>(out->carry);
+        Parted P = partition(src, 1, 1, rb, /*shift0=*/rb ? 32 - rb : 31, /*single pass*/ true, &ext);
+        std::vector<uint32_t> off(n_ranks + 1);
+        RJ_HIP(hipMemcpyAsync(off.data(), P.off->p, (n_ranks + 1) * 4, hipMemcpyDeviceToHost,
+                              ctx->stream));
+        ctx->sync();
+        for (uint32_t r = 0; r < n_ranks; ++r) counts[r] = off[r + 1] - off[r];
+        out->n = off[n_ranks];
+        out->hashed = 1;
+        out->reserved = 0;
+    }
+
+   private:
+    Context*       ctx;
+    const rj_plan* plan;
+    Table* const*  tables;
+    uint64_t       n_tables;
+    int            flags;
+    Launch         L;
+    std::map<std::pair<const Table*, int>, DCol> decoded_;
+    std::map<std::pair<int, int>, std::pair<std::vector<StrView>, std::vector<std::string>>> vc_index_;
+
+    // ------------------------------------------------------------- scan side
+    DCol table_col(const Table* t, int c) {
+        const TableColumn& tc = t->cols[c];
+        DCol               d;
+        d.type = tc.type;
+        d.tcol = &tc;
+        if (tc.type == RJ_VARCHAR) {
+            d.kind = COL_IOTA;
+            d.width = 4;
+            return d;
+        }
+        d.width = tc.type == RJ_INT32 ? 4 : 8;
+        if (tc.regular) {
+            d.kind = COL_PAGED;
+            d.ptr = tc.dev_pages;
+            return d;
+        }
+        auto key = std::make_pair(t, c);
+        auto it = decoded_.find(key);
+        if (it != decoded_.end()) return it->second;
+        // K1: irregular pages (NULLs, short pages) -> dense values + validity
+        uint64_t n = t->num_rows;
+        d.kind = COL_DENSE;
+        d.hold = ctx->buf(n * d.width);
+        d.hold_valid = ctx->buf(n);
+        RJ_HIP(hipMemsetAsync(d.hold->p, 0, n * d.width, ctx->stream));
+        RJ_HIP(hipMemsetAsync(d.hold_valid->p, 0, n, ctx->stream));
+        if (tc.n_pages) {
+            BufP row_base = ctx->buf((tc.n_pages + 1) * 4);
+            launch_scan_bins(L, tc.page_rows->as<uint32_t>(), (uint32_t)tc.n_pages,
+                             row_base->as<uint32_t>(), nullptr);
+            launch_decode_pages(L, tc.dev_pages, (uint32_t)tc.n_pages, d.width,
+                                row_base->as<uint32_t>(), n, d.hold->as<uint8_t>(),
+                                d.hold_valid->as<uint8_t>());
+        }
+        d.ptr = d.hold->as<uint8_t>();
+        d.valid = d.hold_valid->as<uint8_t>();
+        decoded_[key] = d;
+        return d;
+    }
+
+    const Table* table_of(const rj_node& n) {
+        if (n.base_table_id >= n_tables) throw_fmt(RJ_ERR_ARG, "scan: bad base_table_id");
+        return tables[n.base_table_id];
+    }
+
+    // execute_scan (reference src/execute.cpp:284-300): column selection, zero copy
+    Rel scan(const rj_node& n) {
+        const Table* t = table_of(n);
+        Rel          r;
+        r.n = t->num_rows;
+        for (uint64_t k = 0; k < n.n_out; ++k) {
+            uint64_t c = n.out_idx[k];
+            if (c >= t->cols.size()) throw_fmt(RJ_ERR_ARG, "scan: output attr out of range");
+            if (t->cols[c].type != n.out_type[k])
+                throw_fmt(RJ_ERR_ARG, "scan: declared type differs from the column's type");
+            DCol d = table_col(t, (int)c);
+            if (d.type == RJ_VARCHAR) {
+                d.vc_table = (int)n.base_table_id;
+                d.vc_col = (int)c;
+            }
+            r.cols.push_back(d);
+        }
+        return r;
+    }
+
+    // A plan whose root is a Scan: the result pages are the input pages.
+    void root_scan(const rj_node& n, Result& res) {
+        const Table* t = table_of(n);
+        res.num_rows = t->num_rows;
+        for (uint64_t k = 0; k < n.n_out; ++k) {
+            uint64_t c = n.out_idx[k];
+            if (c >= t->cols.size()) throw_fmt(RJ_ERR_ARG, "scan: output attr out of range");
+            const TableColumn& tc = t->cols[c];
+            if (tc.type != n.out_type[k])
+                throw_fmt(RJ_ERR_ARG, "scan: declared type differs from the column's type");
+            ResultColumn rc;
+            rc.type = tc.type;
+            rc.n_pages = tc.n_pages;
+            if (tc.type == RJ_VARCHAR) {
+                rc.host_pages = tc.host_pages;
+                rc.n_pages = tc.host_pages.size() / PAGE_BYTES;
+            } else if (tc.n_pages) {
+                rc.dev_pages = ctx->buf(tc.n_pages * PAGE_BYTES);
+                RJ_HIP(hipMemcpyAsync(rc.dev_pages->p, tc.dev_pages, tc.n_pages * PAGE_BYTES,
+                                      hipMemcpyDeviceToDevice, ctx->stream));
+            }
+            res.cols.push_back(std::move(rc));
+        }
+    }
+
+    // ------------------------------------------------------------- plan walk
+    // execute_impl (reference src/execute.cpp:302-314); children left first (:48-49)
+    Rel node(uint64_t idx, Result* root_res, int depth) {
+        if (idx >= plan->n_nodes) throw_fmt(RJ_ERR_ARG, "bad node index");
+        if (depth > 4096) throw_fmt(RJ_ERR_ARG, "plan too deep (cycle?)");
+        const rj_node& n = plan->nodes[idx];
+        if (n.kind == RJ_NODE_SCAN) return scan(n);
+        if (n.kind != RJ_NODE_JOIN) throw_fmt(RJ_ERR_ARG, "bad node kind");
+        Rel      l = node(n.left, nullptr, depth + 1);
+        Rel      r = node(n.right, nullptr, depth + 1);
+        JoinSpec js;
+        js.build_left = n.build_left != 0;
+        js.left_attr = n.left_attr;
+        js.right_attr = n.right_attr;
+        js.out_idx.assign(n.out_idx, n.out_idx + n.n_out);
+        js.out_type.assign(n.out_type, n.out_type + n.n_out);
+        js.forced_bits = ctx->radix_bits_override;
+        return join_core(l, r, js, root_res);
+    }
+
+    // -------------------------------------------------------- radix partition
+    static uint32_t tiles_per_group(uint64_t tuples_per_segment, uint64_t target_groups) {
+        uint64_t k = (tuples_per_segment + (uint64_t)PT_TILE * target_groups - 1) /
+                     ((uint64_t)PT_TILE * target_groups);
+        return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(k, 1), 8);
+    }
+
+    // `external`: caller-owned arrays that receive the output of a single-pass partition
+    Parted partition(const TupleSrc& src, int KW, int CW, uint32_t bits, uint32_t shift0 = 0,
+                     bool single_pass = false, const Words* external = nullptr) {
+        Parted P;
+        P.NW = KW + CW;
+        const uint64_t n = src.n_rows;
+        uint32_t       passes = single_pass ? 1 : (bits + PT_MAXBITS - 1) / PT_MAXBITS;
+        if (passes == 0) passes = 1;
+        std::vector<uint32_t> pbits(passes, bits / passes);
+        for (uint32_t i = 0; i < bits % passes; ++i) pbits[i]++;
+
+        BufP  A[MAX_WORDS], B[MAX_WORDS];
+        Words wa{}, wb{};
+        for (int a = 0; a < P.NW; ++a) {
+            if (external) {
+                wa.w[a] = external->w[a];
+                continue;
+            }
+            A[a] = ctx->buf(n * 4);
+            wa.w[a] = A[a]->as<uint32_t>();
+            if (passes > 1) {
+                B[a] = ctx->buf(n * 4);
+                wb.w[a] = B[a]->as<uint32_t>();
+            }
+        }
+        BufP     seg_off;  // offsets produced by the previous pass
+        uint32_t nseg = 1, shift = shift0;
+        Words    cur{}, nxt = wa;
+        bool     cur_is_a = false;
+        for (uint32_t p = 0; p < passes; ++p) {
+            const uint32_t F = 1u << pbits[p];
+            const uint64_t bins = (uint64_t)nseg * F;
+            PassParams     pp{};
+            pp.nseg = nseg;
+            pp.n = (uint32_t)n;
+            pp.shift = shift;
+            pp.fanout_log2 = pbits[p];
+            uint32_t n_groups;
+            BufP     grp_start;
+            if (p == 0) {
+                pp.tiles_per_group = tiles_per_group(n, 4096);
+                uint64_t gt = (uint64_t)pp.tiles_per_group * PT_TILE;
+                n_groups = (uint32_t)((n + gt - 1) / gt);
+            } else {
+                pp.tiles_per_group = tiles_per_group(n / nseg + 1, 16);
+                uint64_t gt = (uint64_t)pp.tiles_per_group * PT_TILE;
+                n_groups = (uint32_t)(n / gt + nseg);  // upper bound; exact count lives on device
+                grp_start = ctx->buf(((uint64_t)nseg + 1) * 4);
+                launch_group_table(L, seg_off->as<uint32_t>(), nseg, (uint32_t)gt,
+                                   grp_start->as<uint32_t>());
+                pp.seg_off = seg_off->as<uint32_t>();
+                pp.grp_start = grp_start->as<uint32_t>();
+            }
+            BufP ghist = ctx->buf((uint64_t)std::max<uint32_t>(n_groups, 1) * F * 4);
+            BufP hist = ctx->buf(bins * 4);
+            BufP off = ctx->buf((bins + 1) * 4);
+            BufP cursor = ctx->buf(bins * 4);
+            RJ_HIP(hipMemsetAsync(hist->p, 0, bins * 4, ctx->stream));
+            pp.group_hist = ghist->as<uint32_t>();
+            pp.hist = hist->as<uint32_t>();
+            pp.cursor = cursor->as<uint32_t>();
+            if (p == 0) {
+                launch_pass_hist_src(L, src, KW, pp, n_groups);
+                launch_scan_bins(L, pp.hist, (uint32_t)bins, off->as<uint32_t>(), pp.cursor);
+                launch_pass_scatter_src(L, src, KW, CW, pp, n_groups, nxt);
+            } else {
+                launch_pass_hist_dense(L, cur, pp, n_groups);
+                launch_scan_bins(L, pp.hist, (uint32_t)bins, off->as<uint32_t>(), pp.cursor);
+                launch_pass_scatter_dense(L, cur, P.NW, pp, n_groups, nxt);
+            }
+            seg_off = off;
+            nseg = (uint32_t)bins;
+            shift += pbits[p];
+            cur = nxt;
+            cur_is_a = (p % 2 == 0);
+            nxt = cur_is_a ? wb : wa;
+        }
+        P.w = cur;
+        for (int a = 0; a < P.NW; ++a) P.wbuf[a] = cur_is_a ? A[a] : B[a];
+        P.off = seg_off;
+        P.NP = nseg;
+        return P;
+    }
+
+    // ---------------------------------------------------------------- join
+    struct Side {
+        Rel*          rel = nullptr;
+        uint64_t      key_col = 0;
+        std::set<int> need;       // referenced columns that are not served by the key stream
+        int           carry_mode = CARRY_NONE;
+        int           carry_col = -1;
+        int           CW = 0;
+        BufP          stream;     // emitted carry stream
+        int           stream_mode = ST_NONE;
+    };
+
+    static uint64_t pages_for(uint64_t rows, int width) {
+        uint64_t rf = width == 4 ? ROWS32 : ROWS64;
+        return (rows + rf - 1) / rf;
+    }
+
+    Rel empty_rel(const JoinSpec& js, Result* root_res) {
+        Rel r;
+        r.n = 0;
+        for (size_t k = 0; k < js.out_type.size(); ++k) {
+            DCol d;
+            d.type = js.out_type[k];
+            d.kind = COL_DENSE;
+            d.width = d.type == RJ_INT32 || d.type == RJ_VARCHAR ? 4 : 8;
+            r.cols.push_back(d);
+        }
+        if (root_res) {
+            root_res->num_rows = 0;
+            for (size_t k = 0; k < js.out_type.size(); ++k) {
+                ResultColumn rc;
+                rc.type = js.out_type[k];
+                root_res->cols.push_back(std::move(rc));
+            }
+        }
+        return r;
+    }
+
+    // execute_hash_join + hash_join_omp (reference src/execute.cpp:43-282)
+    Rel join_core(Rel& left, Rel& right, const JoinSpec& js, Result* root_res) {
+        const size_t lw = left.cols.size(), rw = right.cols.size();
+        const bool   is_root = root_res != nullptr;
+        // with an empty child the reference returns {} before looking at anything (:50)
+        if (left.n == 0 || right.n == 0) return empty_rel(js, root_res);
+        if (js.left_attr >= lw || js.right_attr >= rw)
+            throw_fmt(RJ_ERR_ARG, "join: key attr out of range");
+        for (size_t k = 0; k < js.out_idx.size(); ++k) {
+            if (js.out_idx[k] >= lw + rw) throw_fmt(RJ_ERR_ARG, "join: output attr out of range");
+            const DCol& c = js.out_idx[k] < lw ? left.cols[js.out_idx[k]]
+                                               : right.cols[js.out_idx[k] - lw];
+            if (c.type != js.out_type[k])
+                throw_fmt(RJ_ERR_ARG, "join: declared type differs from the child column's type");
+        }
+        Side  ls, rs;
+        ls.rel = &left;
+        ls.key_col = js.left_attr;
+        rs.rel = &right;
+        rs.key_col = js.right_attr;
+        Side&       bs = js.build_left ? ls : rs;
+        Side&       ps = js.build_left ? rs : ls;
+        const DCol& bk = bs.rel->cols[bs.key_col];
+        const DCol& pk = ps.rel->cols[ps.key_col];
+        // KeyType = build side's key type (:271-273)
+        if (bk.type == RJ_VARCHAR)
+            throw_fmt(RJ_ERR_UNSUPPORTED,
+                      "VARCHAR join keys are not supported on the GPU path (never a JOB join key)");
+        if (bk.type < RJ_INT32 || bk.type > RJ_VARCHAR) throw_fmt(RJ_ERR_ARG, "Unsupported join type");
+        // probe values of another variant alternative are never valid (:65-71)
+        if (pk.type != bk.type) return empty_rel(js, root_res);
+        const int  KW = bk.type == RJ_INT32 ? 1 : 2;
+        const bool f64 = bk.type == RJ_FP64;
+        // matching keys are bit-identical on both sides (FP64 included: bit-pattern equality,
+        // see SrcLoader::key2), so one emitted key stream serves either side's key column
+        const bool key_stream_ok = true;
+
+        // which child columns must each side deliver?
+        bool need_key_stream = false;
+        for (size_t k = 0; k < js.out_idx.size(); ++k) {
+            bool  is_left = js.out_idx[k] < lw;
+            Side& s = is_left ? ls : rs;
+            int   c = (int)(is_left ? js.out_idx[k] : js.out_idx[k] - lw);
+            if (key_stream_ok && (uint64_t)c == s.key_col)
+                need_key_stream = true;
+            else
+                s.need.insert(c);
+        }
+        for (Side* s : {&ls, &rs}) {
+            if (s->need.empty()) {
+                s->carry_mode = CARRY_NONE;
+                s->CW = 0;
+            } else if (s->need.size() == 1 && s->rel->cols[*s->need.begin()].valid == nullptr) {
+                s->carry_mode = CARRY_COLUMN;
+                s->carry_col = *s->need.begin();
+                s->CW = s->rel->cols[s->carry_col].width / 4;
+            } else {
+                s->carry_mode = CARRY_ROWIDX;
+                s->CW = 1;
+            }
+        }
+
+        // radix bit plan from the build cardinality
+        uint32_t bits = js.forced_bits > 0
+                            ? (uint32_t)js.forced_bits
+                            : ceil_log2((bs.rel->n + JN_TARGET_BUILD - 1) / JN_TARGET_BUILD);
+        bits = std::min<uint32_t>(std::max<uint32_t>(bits, 1), 27);
+
+        auto make_src = [&](Side& s) {
+            TupleSrc src{};
+            src.key = s.rel->cols[s.key_col].ref();
+            src.n_rows = (uint32_t)s.rel->n;
+            src.carry_mode = s.carry_mode;
+            if (s.carry_mode == CARRY_COLUMN) src.carry = s.rel->cols[s.carry_col].ref();
+            src.key_f64 = f64 ? 1 : 0;
+            src.prehashed = js.prehashed ? 1 : 0;
+            return src;
+        };
+        Parted PB = partition(make_src(bs), KW, bs.CW, bits);
+        Parted PP = partition(make_src(ps), KW, ps.CW, bits);
+
+        // heavy probe partitions -> task list
+        uint32_t max_tasks = (uint32_t)(2 * (ps.rel->n / JN_HEAVY) + 2);
+        BufP     tasks = ctx->buf((uint64_t)max_tasks * 12);
+        BufP     counters = ctx->buf(16);  // [0..7] out cursor (u64), [8..11] n_heavy
+        launch_heavy_tasks_zeroed(PB, PP, tasks, counters, max_tasks);
+
+        // stream destinations
+        auto stream_mode = [&](int width, bool direct_output) -> int {
+            if (is_root && direct_output) return width == 4 ? ST_PAGED32 : ST_PAGED64;
+            return width == 4 ? ST_DENSE32 : ST_DENSE64;
+        };
+        auto stream_bytes = [&](int mode, uint64_t rows) -> uint64_t {
+            switch (mode) {
+            case ST_DENSE32: return rows * 4;
+            case ST_DENSE64: return rows * 8;
+            case ST_PAGED32: return pages_for(rows, 4) * PAGE_BYTES;
+            case ST_PAGED64: return pages_for(rows, 8) * PAGE_BYTES;
+            default: return 0;
+            }
+        };
+        int key_mode = need_key_stream ? stream_mode(KW * 4, true) : ST_NONE;
+        for (Side* s : {&ls, &rs}) {
+            if (s->carry_mode == CARRY_NONE)
+                s->stream_mode = ST_NONE;
+            else if (s->carry_mode == CARRY_ROWIDX)
+                s->stream_mode = ST_DENSE32;
+            else {
+                const DCol& c = s->rel->cols[s->carry_col];
+                s->stream_mode = stream_mode(c.width, c.type != RJ_VARCHAR);
+            }
+        }
+
+        uint64_t cap = std::max(left.n, right.n);
+        cap = std::min<uint64_t>(cap + 1024, 0xfffffff0ull);
+        BufP     key_stream;
+        uint64_t nrows = 0;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            key_stream = key_mode != ST_NONE ? ctx->buf(stream_bytes(key_mode, cap)) : BufP();
+            for (Side* s : {&ls, &rs})
+                s->stream = s->stream_mode != ST_NONE ? ctx->buf(stream_bytes(s->stream_mode, cap))
+                                                      : BufP();
+            RJ_HIP(hipMemsetAsync(counters->p, 0, 8, ctx->stream));
+            JoinParams jp{};
+            jp.R = PB.w;
+            jp.S = PP.w;
+            jp.offR = PB.off->as<uint32_t>();
+            jp.offS = PP.off->as<uint32_t>();
+            jp.NP = PB.NP;
+            jp.radix_bits = bits;
+            jp.key = OutStream{key_stream ? key_stream->as<uint8_t>() : nullptr, key_mode, 0};
+            jp.bc = OutStream{bs.stream ? bs.stream->as<uint8_t>() : nullptr, bs.stream_mode, 0};
+            jp.pc = OutStream{ps.stream ? ps.stream->as<uint8_t>() : nullptr, ps.stream_mode, 0};
+            jp.out_cursor = counters->as<unsigned long long>();
+            jp.out_cap = cap;
+            jp.heavy_tasks = tasks->as<uint32_t>();
+            jp.n_heavy = counters->as<uint32_t>() + 2;
+            jp.heavy_pass = 0;
+            launch_join(L, KW, bs.CW, ps.CW, jp, PB.NP);
+            jp.heavy_pass = 1;
+            launch_join(L, KW, bs.CW, ps.CW, jp, max_tasks);
+            unsigned long long h = 0;
+            RJ_HIP(hipMemcpyAsync(&h, counters->p, 8, hipMemcpyDeviceToHost, ctx->stream));
+            ctx->sync();
+            nrows = h;
+            if (nrows <= cap) break;
+            if (nrows > 0xfffffff0ull)
+                throw_fmt(RJ_ERR_UNSUPPORTED, "join result exceeds 2^32 rows (%llu)", h);
+            if (attempt == 1) throw_fmt(RJ_ERR_DEVICE, "join output overflowed twice");
+            cap = nrows;  // exact size, run the probe again
+        }
+
+        // ------------------------------------------------ assemble the outputs
+        Rel out;
+        out.n = nrows;
+        if (is_root) root_res->num_rows = nrows;
+        std::set<void*> finished;  // paged buffers that already got headers
+        for (size_t k = 0; k < js.out_idx.size(); ++k) {
+            bool        is_left = js.out_idx[k] < lw;
+            Side&       s = is_left ? ls : rs;
+            int         c = (int)(is_left ? js.out_idx[k] : js.out_idx[k] - lw);
+            const DCol& src = s.rel->cols[c];
+            DCol        d;
+            d.type = src.type;
+            d.width = src.width;
+            d.kind = COL_DENSE;
+            d.vc_table = src.vc_table;
+            d.vc_col = src.vc_col;
+            BufP buf;           // where this column's values/pages live
+            int  buf_mode = ST_NONE;
+            BufP valid;
+            if (key_stream_ok && (uint64_t)c == s.key_col) {
+                buf = key_stream;
+                buf_mode = key_mode;
+            } else if (s.carry_mode == CARRY_COLUMN) {
+                buf = s.stream;
+                buf_mode = s.stream_mode;
+            } else {
+                // generic path: gather the child column through the row-index stream
+                const uint32_t* idx = s.stream->as<uint32_t>();
+                if (src.kind == COL_IOTA) {
+                    buf = s.stream;  // row ids of the base table ARE the stream
+                    buf_mode = ST_DENSE32;
+                } else {
+                    bool to_pages = is_root && src.type != RJ_VARCHAR && src.valid == nullptr;
+                    buf_mode = to_pages ? (src.width == 4 ? ST_PAGED32 : ST_PAGED64)
+                                        : (src.width == 4 ? ST_DENSE32 : ST_DENSE64);
+                    buf = ctx->buf(stream_bytes(buf_mode, std::max<uint64_t>(nrows, 1)));
+                    if (src.valid) valid = ctx->buf(std::max<uint64_t>(nrows, 1));
+                    launch_gather(L, src.ref(), idx, nrows,
+                                  OutStream{buf->as<uint8_t>(), buf_mode, 0},
+                                  valid ? valid->as<uint8_t>() : nullptr);
+                }
+            }
+            if (!is_root) {
+                d.hold = buf;
+                d.ptr = buf ? buf->as<uint8_t>() : nullptr;
+                d.hold_valid = valid;
+                d.valid = valid ? valid->as<uint8_t>() : nullptr;
+                out.cols.push_back(d);
+                continue;
+            }
+            // ---- root: Page images (replaces Table::to_columnar, build_table.cpp:456-681)
+            ResultColumn rc;
+            rc.type = src.type;
+            if (nrows == 0) {
+                // empty result: typed columns with zero pages (reference tests/unit_tests.cpp:24-27)
+            } else if (src.type == RJ_VARCHAR) {
+                varchar_root(buf->as<uint32_t>(), nrows, src, rc);
+            } else if (buf_mode == ST_PAGED32 || buf_mode == ST_PAGED64) {
+                if (!finished.count(buf->p)) {
+                    launch_finish_pages(L, buf->as<uint8_t>(), nrows, src.width);
+                    finished.insert(buf->p);
+                }
+                rc.dev_pages = buf;
+                rc.n_pages = pages_for(nrows, src.width);
+            } else {
+                // dense values (+ validity): encode pages on the device
+                rc.n_pages = pages_for(nrows, src.width);
+                rc.dev_pages = ctx->buf(rc.n_pages * PAGE_BYTES);
+                if (valid) {
+                    launch_encode_nullable(L, buf->as<uint8_t>(), valid->as<uint8_t>(), nrows,
+                                           src.width, rc.dev_pages->as<uint8_t>());
+                } else {
+                    DCol dense;
+                    dense.kind = COL_DENSE;
+                    dense.width = src.width;
+                    dense.ptr = buf->as<uint8_t>();
+                    launch_gather(L, dense.ref(), nullptr, nrows,
+                                  OutStream{rc.dev_pages->as<uint8_t>(),
+                                            src.width == 4 ? ST_PAGED32 : ST_PAGED64, 0},
+                                  nullptr);
+                    launch_finish_pages(L, rc.dev_pages->as<uint8_t>(), nrows, src.width);
+                }
+            }
+            root_res->cols.push_back(std::move(rc));
+        }
+        return out;
+    }
+
+    void launch_heavy_tasks_zeroed(const Parted& PB, const Parted& PP, const BufP& tasks,
+                                   const BufP& counters, uint32_t max_tasks) {
+        RJ_HIP(hipMemsetAsync(counters->p, 0, 16, ctx->stream));
+        launch_heavy_tasks(L, PB.off->as<uint32_t>(), PP.off->as<uint32_t>(), PB.NP,
+                           tasks->as<uint32_t>(), counters->as<uint32_t>() + 2, max_tasks);
+    }
+
+    // VARCHAR at the root: row ids -> host, strings gathered from the base table's
+    // pages and encoded with the reference's fill rule (build_table.cpp:595-677).
+    void varchar_root(const uint32_t* dev_rowids, uint64_t n, const DCol& src, ResultColumn& rc) {
+        if (src.vc_table < 0 || (uint64_t)src.vc_table >= n_tables)
+            throw_fmt(RJ_ERR_ARG, "VARCHAR column without provenance");
+        const Table*       t = tables[src.vc_table];
+        const TableColumn& tc = t->cols[src.vc_col];
+        std::vector<uint32_t> ids(n);
+        RJ_HIP(hipMemcpyAsync(ids.data(), dev_rowids, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->sync();
+        auto  key = std::make_pair(src.vc_table, src.vc_col);
+        auto  it = vc_index_.find(key);
+        if (it == vc_index_.end()) {
+            it = vc_index_.emplace(key, std::make_pair(std::vector<StrView>(), std::vector<std::string>()))
+                     .first;
+            varchar_index(tc.host_pages.data(), tc.host_pages.size() / PAGE_BYTES, t->num_rows,
+                          it->second.first, it->second.second);
+        }
+        varchar_gather_encode(it->second.first, ids.data(), n, rc.host_pages, rc.n_pages);
+    }
+};
+
+}  // namespace
+
+Result* execute_plan(Context* ctx, const rj_plan* plan, Table* const* tables, uint64_t n_tables,
+                     int flags) {
+    Exec e(ctx, plan, tables, n_tables, flags);
+    return e.run();
+}
+
+Result* join_tuples(Context* ctx, const rj_tuples* build, const rj_tuples* probe,
+                    uint32_t skip_rank_bits, int flags) {
+    Exec e(ctx, nullptr, nullptr, 0, flags);
+    return e.run_tuples(build, probe, skip_rank_bits);
+}
+
+void shard_partition(Context* ctx, const Table* t, uint64_t key_col, uint64_t carry_col,
+                     uint32_t n_ranks, rj_tuples* out, uint64_t* counts) {
+    Exec e(ctx, nullptr, nullptr, 0, 0);
+    e.run_shard(t, key_col, carry_col, n_ranks, out, counts);
+}
+
+}  // namespace rj

@@ -1,0 +1,208 @@
+// rj_internal.hpp — host-side runtime of librj.so: context, HBM block cache,
+// per-kernel HIP-event profiler, resident tables and results.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/rj.h"
+#include "rj_device.hpp"
+#include "rj_kernels.hpp"
+
+namespace rj {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+[[noreturn]] inline void throw_fmt(int code, const char* fmt, ...) {
+    char    buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    throw Error(code, buf);
+}
+
+#define RJ_HIP(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            ::rj::throw_fmt(_e == hipErrorOutOfMemory ? RJ_ERR_NOMEM : RJ_ERR_DEVICE,         \
+                            "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                            __LINE__);                                                        \
+    } while (0)
+
+// ---------------------------------------------------------------- HBM cache --
+// hipMalloc/hipFree of multi-GB buffers cost milliseconds and synchronise; the
+// context keeps freed blocks and hands them out again.  All work of a context
+// runs on ONE stream, so reuse is ordered by the stream.
+class DevPool {
+   public:
+    void* alloc(size_t bytes);
+    void  release(void* p);
+    void  trim();  // hipFree everything that is not in use
+    ~DevPool();
+    size_t bytes_in_use() const { return in_use_; }
+    size_t bytes_cached() const { return cached_; }
+
+   private:
+    struct Block {
+        void*  p;
+        size_t size;
+        bool   free;
+    };
+    std::vector<Block> blocks_;
+    size_t             in_use_ = 0, cached_ = 0;
+};
+
+struct Context;
+
+// RAII device buffer drawn from the context's cache.
+struct Buf {
+    Context* ctx = nullptr;
+    void*    p = nullptr;
+    size_t   bytes = 0;
+    Buf(Context* c, size_t n);
+    ~Buf();
+    Buf(const Buf&) = delete;
+    Buf& operator=(const Buf&) = delete;
+    template <class T>
+    T* as() const {
+        return reinterpret_cast<T*>(p);
+    }
+};
+using BufP = std::shared_ptr<Buf>;
+
+// ----------------------------------------------------------------- profiler --
+class Profiler {
+   public:
+    bool        on = false;
+    hipStream_t stream = nullptr;
+    void        begin(const char* name);
+    void        end();
+    void        drain();  // synchronises, folds finished records into totals
+    void        reset();
+    struct Tot {
+        uint64_t launches = 0;
+        double   ms = 0;
+    };
+    std::map<std::string, Tot> totals;
+    std::vector<std::string>   order;
+    ~Profiler();
+
+   private:
+    struct Rec {
+        const char* name;
+        hipEvent_t  a, b;
+    };
+    std::vector<Rec>        open_;
+    std::vector<hipEvent_t> spare_;
+    hipEvent_t              get_event();
+};
+
+// ------------------------------------------------------------------- tables --
+struct TableColumn {
+    int32_t  type = 0;
+    uint64_t n_pages = 0;
+    // fixed-width columns: page images in HBM
+    const uint8_t* dev_pages = nullptr;
+    BufP           owned;          // set when the table owns the images (upload)
+    bool           regular = false; // addressable in place (see ColKind::COL_PAGED)
+    uint64_t       page_rows_total = 0;
+    BufP           page_rows;      // u32[n_pages] rows per page (for K1)
+    // VARCHAR columns: host page images (a private copy)
+    std::vector<uint8_t> host_pages;
+};
+
+struct Table {
+    Context*                 ctx = nullptr;
+    uint64_t                 num_rows = 0;
+    std::vector<TableColumn> cols;
+};
+
+// ------------------------------------------------------------------ results --
+struct ResultColumn {
+    int32_t              type = 0;
+    uint64_t             n_pages = 0;
+    BufP                 dev_pages;   // fixed-width
+    std::vector<uint8_t> host_pages;  // VARCHAR (encoded on the host)
+};
+
+struct Result {
+    Context*                  ctx = nullptr;
+    uint64_t                  num_rows = 0;
+    std::vector<ResultColumn> cols;
+};
+
+// ------------------------------------------------------------------ context --
+struct Context {
+    int         device = 0;
+    hipStream_t stream = nullptr;
+    bool        own_stream = false;
+    int         radix_bits_override = 0;
+    DevPool     pool;
+    Profiler    prof;
+    std::string last_error;
+    // pinned staging for H2D / D2H of page images
+    void*  pinned = nullptr;
+    size_t pinned_bytes = 0;
+    void*  pinned_small = nullptr;  // 4 KiB for counters
+    Launch launch() {
+        Launch L;
+        L.stream = stream;
+        L.self = this;
+        L.begin = prof.on ? [](void* s, const char* n) { static_cast<Context*>(s)->prof.begin(n); }
+                          : (void (*)(void*, const char*)) nullptr;
+        L.end = prof.on ? [](void* s) { static_cast<Context*>(s)->prof.end(); }
+                        : (void (*)(void*)) nullptr;
+        return L;
+    }
+    BufP  buf(size_t bytes) { return std::make_shared<Buf>(this, bytes ? bytes : 16); }
+    void* staging(size_t bytes);
+    void  sync() { RJ_HIP(hipStreamSynchronize(stream)); }
+    ~Context();
+};
+
+// rj_exec.hip
+Result* execute_plan(Context* ctx, const rj_plan* plan, Table* const* tables, uint64_t n_tables,
+                     int flags);
+Result* join_tuples(Context* ctx, const rj_tuples* build, const rj_tuples* probe,
+                    uint32_t skip_rank_bits, int flags);
+void    shard_partition(Context* ctx, const Table* t, uint64_t key_col, uint64_t carry_col,
+                        uint32_t n_ranks, rj_tuples* out, uint64_t* counts);
+
+// rj_table.hip
+Table* table_upload(Context* ctx, const rj_input* host);
+Table* table_adopt(Context* ctx, uint64_t num_rows, uint64_t n_cols, const int32_t* types,
+                   const void* const* dev_pages, const uint64_t* n_pages);
+void   result_copy_pages(Result* r, uint64_t col, void* const* dst, uint64_t n_dst);
+
+// rj_varchar.cpp (host only)
+// Decode a VARCHAR column's pages into (pointer,length) views, one per row; NULL rows get
+// ptr == nullptr.  `stitch` owns long strings that span pages.
+struct StrView {
+    const char* p;
+    uint32_t    len;
+};
+void varchar_index(const uint8_t* pages, uint64_t n_pages, uint64_t num_rows,
+                   std::vector<StrView>& rows, std::vector<std::string>& stitch);
+// Gather rows[idx[i]] and encode them as VARCHAR pages (reference fill rule
+// src/build_table.cpp:595-677).
+void varchar_gather_encode(const std::vector<StrView>& rows, const uint32_t* idx, uint64_t n,
+                           std::vector<uint8_t>& out_pages, uint64_t& n_pages);
+
+}  // namespace rj
+
+// Opaque C handles
+struct rj_context : rj::Context {};
+struct rj_table : rj::Table {};
+struct rj_result : rj::Result {};

@@ -1,0 +1,901 @@
+// rj_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the radix join.
+//
+// Everything here is integer / indexing work bound by HBM bandwidth (no MFMA):
+//   K0  page headers        4 B read per 8 KiB page
+//   K1  page decode         irregular (NULL-bearing) pages -> dense values + validity
+//   K2  pass histogram      per-workgroup LDS histogram, flushed once per tile group
+//   K3  bin scan            single workgroup, wave-shuffle scan
+//   K4  pass scatter        tile sorted by digit in LDS (LDS atomics give the rank), runs
+//                           written out contiguously = software write-combining
+//   K5/6 build + probe      per-partition linear-probing table in LDS, ballot/mbcnt
+//                           output offsets, one global reservation per 4096 probe tuples
+//   K7  gather              row-id -> column value (generic late materialisation)
+//   K8  page finish/encode  Page headers + validity bitmaps of the result
+//
+// Reference counterparts are cited at each kernel (paths relative to the reference).
+#include "rj_kernels.hpp"
+
+namespace rj {
+
+// ============================================================== small helpers
+// Bijective finalisers (murmur3 fmix32 / fmix64).  The reference hashes with
+// fmix64 (src/execute.cpp:21-27); the hash is not observable in results
+// (SURVEY.md §2 #11), so INT32 keys use the cheaper 32-bit mix.  Because both
+// are bijections the partitions store HASHED keys and the probe un-hashes on
+// emit; equal hashed keys <=> equal keys.
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ uint32_t unfmix32(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x7ed1b41du;  // inverse of 0xc2b2ae35 mod 2^32
+    h ^= (h >> 13) ^ (h >> 26);
+    h *= 0xa5cb9243u;  // inverse of 0x85ebca6b mod 2^32
+    h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ uint64_t fmix64(uint64_t k) {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdULL;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ULL;
+    k ^= k >> 33;
+    return k;
+}
+__device__ __forceinline__ uint64_t unfmix64(uint64_t k) {
+    k ^= k >> 33;
+    k *= 0x9cb4b2f8129337dbULL;  // inverse of 0xc4ceb9fe1a85ec53 mod 2^64
+    k ^= k >> 33;
+    k *= 0x4f74430c22a54005ULL;  // inverse of 0xff51afd7ed558ccd mod 2^64
+    k ^= k >> 33;
+    return k;
+}
+
+// lanes below me whose bit is set in `mask` (wave64)
+__device__ __forceinline__ uint32_t lane_prefix(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                     __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// Exclusive scan of one value per thread across the workgroup (blockDim.x a
+// multiple of 64, at most 1024).  s_wsum needs blockDim.x/64 words.  Contains
+// one __syncthreads(); the caller must sync again before reusing s_wsum.
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_wsum, uint32_t& total) {
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    uint32_t       incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t t = __shfl_up(incl, off);
+        if (lane >= (uint32_t)off) incl += t;
+    }
+    if (lane == 63) s_wsum[wid] = incl;
+    __syncthreads();
+    uint32_t wbase = 0, tot = 0;
+    for (uint32_t k = 0; k < nw; ++k) {
+        uint32_t s = s_wsum[k];
+        if (k < wid) wbase += s;
+        tot += s;
+    }
+    total = tot;
+    return wbase + incl - v;
+}
+
+__device__ __forceinline__ uint32_t col_load32(const ColRef& c, uint32_t row) {
+    if (c.kind == COL_PAGED) {
+        uint32_t p = row / ROWS32, i = row - p * ROWS32;
+        return *reinterpret_cast<const uint32_t*>(c.ptr + (size_t)p * PAGE_BYTES + HDR32 + i * 4u);
+    } else if (c.kind == COL_DENSE) {
+        return reinterpret_cast<const uint32_t*>(c.ptr)[row];
+    }
+    return row;  // COL_IOTA
+}
+__device__ __forceinline__ uint64_t col_load64(const ColRef& c, uint32_t row) {
+    if (c.kind == COL_PAGED) {
+        uint32_t p = row / ROWS64, i = row - p * ROWS64;
+        return *reinterpret_cast<const uint64_t*>(c.ptr + (size_t)p * PAGE_BYTES + HDR64 + i * 8u);
+    } else if (c.kind == COL_DENSE) {
+        return reinterpret_cast<const uint64_t*>(c.ptr)[row];
+    }
+    return row;
+}
+
+__device__ __forceinline__ void stream_store(const OutStream& o, uint64_t row, uint32_t lo,
+                                             uint32_t hi) {
+    switch (o.mode) {
+    case ST_DENSE32: reinterpret_cast<uint32_t*>(o.base)[row] = lo; break;
+    case ST_DENSE64:
+        reinterpret_cast<uint64_t*>(o.base)[row] = (uint64_t)lo | ((uint64_t)hi << 32);
+        break;
+    case ST_PAGED32: {
+        uint32_t r = (uint32_t)row, p = r / ROWS32, i = r - p * ROWS32;
+        *reinterpret_cast<uint32_t*>(o.base + (size_t)p * PAGE_BYTES + HDR32 + i * 4u) = lo;
+        break;
+    }
+    case ST_PAGED64: {
+        uint32_t r = (uint32_t)row, p = r / ROWS64, i = r - p * ROWS64;
+        *reinterpret_cast<uint64_t*>(o.base + (size_t)p * PAGE_BYTES + HDR64 + i * 8u) =
+            (uint64_t)lo | ((uint64_t)hi << 32);
+        break;
+    }
+    default: break;
+    }
+}
+
+// ================================================================= K0 headers
+// Reads `u16 n_rows @0, u16 n_nonnull @2` of every page (layout: reference
+// src/build_table.cpp:326-329).  A column is "regular" when every page but the
+// last holds exactly rows_full non-NULL rows; regular columns are addressed in
+// place by every later kernel, the others go through K1 once.
+__global__ void k_page_headers(const uint8_t* pages, uint32_t n_pages, uint32_t rows_full,
+                               uint32_t* page_rows, unsigned long long* flags) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pages) return;
+    uint32_t hdr = *reinterpret_cast<const uint32_t*>(pages + (size_t)p * PAGE_BYTES);
+    uint32_t nr = hdr & 0xffffu, nv = hdr >> 16;
+    page_rows[p] = nr;
+    bool irregular = (nv != nr) || (p + 1 < n_pages ? nr != rows_full : (nr > rows_full || nr == 0));
+    if (irregular) atomicAdd(&flags[0], 1ull);
+    atomicAdd(&flags[1], (unsigned long long)nr);
+}
+
+// ================================================================== K1 decode
+// One workgroup per page: rows -> dense values + validity bytes.  The value
+// index of row i is the number of set validity bits below i (values are stored
+// densely, the bitmap sits in the last (n_rows+7)/8 bytes: reference
+// src/build_table.cpp:325-381).  Per 64 rows one ballot + mbcnt.
+template <int WIDTH>
+__global__ __launch_bounds__(256) void k_decode_pages(const uint8_t* pages, const uint32_t* row_base,
+                                                      uint64_t num_rows, uint8_t* values,
+                                                      uint8_t* valid) {
+    __shared__ uint32_t s_w[4];
+    const uint8_t*      page = pages + (size_t)blockIdx.x * PAGE_BYTES;
+    const uint32_t      nr = *reinterpret_cast<const uint16_t*>(page);
+    const uint32_t      rb = row_base[blockIdx.x];
+    const uint8_t*      bitmap = page + PAGE_BYTES - (nr + 7) / 8;
+    const uint8_t*      vals = page + (WIDTH == 4 ? HDR32 : HDR64);
+    const uint32_t      lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    uint32_t            running = 0;
+    for (uint32_t base = 0; base < nr; base += 256) {
+        uint32_t i = base + threadIdx.x;
+        bool     bit = i < nr ? ((bitmap[i >> 3] >> (i & 7u)) & 1u) : false;
+        uint64_t mask = __ballot(bit);
+        uint32_t pre = lane_prefix(mask);
+        if (lane == 0) s_w[wid] = (uint32_t)__popcll(mask);
+        __syncthreads();
+        uint32_t wpre = 0, tot = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            uint32_t c = s_w[k];
+            if (k < wid) wpre += c;
+            tot += c;
+        }
+        uint64_t row = (uint64_t)rb + i;
+        if (i < nr && row < num_rows) {
+            valid[row] = bit ? 1 : 0;
+            uint32_t vi = running + wpre + pre;
+            if (WIDTH == 4) {
+                reinterpret_cast<uint32_t*>(values)[row] =
+                    bit ? reinterpret_cast<const uint32_t*>(vals)[vi] : 0u;
+            } else {
+                reinterpret_cast<uint64_t*>(values)[row] =
+                    bit ? reinterpret_cast<const uint64_t*>(vals)[vi] : 0ull;
+            }
+        }
+        running += tot;
+        __syncthreads();
+    }
+}
+
+// ==================================================================== K3 scan
+// Single workgroup of 1024 threads; thread t owns a contiguous chunk.
+// MODE 0: v[i] = in[i].  MODE 1: v[i] = ceil((in[i+1]-in[i]) / div)  (group table)
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_scan_bins(const uint32_t* in, uint32_t n, uint32_t div,
+                                                    uint32_t* off, uint32_t* cursor) {
+    __shared__ uint32_t s_wsum[16];
+    const uint32_t      chunk = (n + 1023u) / 1024u;
+    const uint32_t      b = threadIdx.x * chunk;
+    const uint32_t      e = min(n, b + chunk);
+    uint32_t            sum = 0;
+    for (uint32_t i = b; i < e; ++i) {
+        uint32_t v = MODE == 0 ? in[i] : (in[i + 1] - in[i] + div - 1u) / div;
+        sum += v;
+    }
+    uint32_t total;
+    uint32_t run = block_excl_scan(sum, s_wsum, total);
+    for (uint32_t i = b; i < e; ++i) {
+        uint32_t v = MODE == 0 ? in[i] : (in[i + 1] - in[i] + div - 1u) / div;
+        off[i] = run;
+        if (cursor) cursor[i] = run;
+        run += v;
+    }
+    if (threadIdx.x == 0) off[n] = total;
+}
+
+// ========================================================== tuple loaders (K2/K4)
+// Loader concept:  key(i, hk) -> valid      load<NW>(i, w) -> valid
+struct DenseLoader {
+    Words in;
+    __device__ __forceinline__ bool key(uint32_t i, uint32_t& hk) const {
+        hk = in.w[0][i];
+        return true;
+    }
+    template <int NW>
+    __device__ __forceinline__ bool load(uint32_t i, uint32_t (&w)[NW]) const {
+#pragma unroll
+        for (int a = 0; a < NW; ++a) w[a] = in.w[a][i];
+        return true;
+    }
+};
+
+// Forms tuples straight from columns: page decode (regular pages), NULL-key
+// drop (reference src/execute.cpp:62-83: only rows whose variant holds KeyType
+// are valid) and hashing fused into the first radix pass.
+template <int KW, int CW>
+struct SrcLoader {
+    TupleSrc s;
+    __device__ __forceinline__ bool key2(uint32_t row, uint32_t& lo, uint32_t& hi) const {
+        if (s.key.valid && !s.key.valid[row]) return false;
+        if (KW == 1) {
+            uint32_t k = col_load32(s.key, row);
+            lo = s.prehashed ? k : fmix32(k);
+            hi = 0;
+            return true;
+        }
+        uint64_t k = col_load64(s.key, row);
+        if (s.key_f64) {
+            // The reference hashes the BIT PATTERN of a double (src/execute.cpp:28-31) and
+            // compares with == (:215,231): NaN equals nothing, and -0.0 / +0.0 hash to
+            // different slots so they only meet by accident of probing.  Bit-pattern
+            // equality with NaN excluded reproduces that (SURVEY.md §8a note on FP64).
+            if ((k & 0x7ff0000000000000ull) == 0x7ff0000000000000ull && (k & 0x000fffffffffffffull))
+                return false;
+        }
+        uint64_t h = fmix64(k);
+        lo = (uint32_t)h;
+        hi = (uint32_t)(h >> 32);
+        return true;
+    }
+    __device__ __forceinline__ bool key(uint32_t row, uint32_t& hk) const {
+        uint32_t hi;
+        return key2(row, hk, hi);
+    }
+    template <int NW>
+    __device__ __forceinline__ bool load(uint32_t row, uint32_t (&w)[NW]) const {
+        static_assert(NW == KW + CW, "word count");
+        uint32_t lo, hi;
+        if (!key2(row, lo, hi)) return false;
+        w[0] = lo;
+        if (KW == 2) w[1] = hi;
+        if constexpr (CW >= 1) {
+            if (s.carry_mode == CARRY_ROWIDX) {
+                w[KW] = row;  // CW == 1 by construction
+            } else if constexpr (CW == 1) {
+                w[KW] = col_load32(s.carry, row);
+            } else {
+                uint64_t v = col_load64(s.carry, row);
+                w[KW] = (uint32_t)v;
+                w[KW + 1] = (uint32_t)(v >> 32);
+            }
+        }
+        return true;
+    }
+};
+
+// Which tuples does workgroup `g` own?  A group is up to tiles_per_group
+// consecutive tiles inside ONE input segment.
+__device__ __forceinline__ bool group_range(const PassParams& pp, uint32_t g, uint32_t& seg,
+                                            uint32_t& begin, uint32_t& end) {
+    const uint32_t gt = pp.tiles_per_group * (uint32_t)PT_TILE;
+    if (pp.seg_off == nullptr) {
+        seg = 0;
+        uint64_t b = (uint64_t)g * gt;
+        if (b >= pp.n) return false;
+        begin = (uint32_t)b;
+        end = (uint32_t)min((uint64_t)pp.n, b + gt);
+        return true;
+    }
+    if (g >= pp.grp_start[pp.nseg]) return false;
+    uint32_t lo = 0, hi = pp.nseg;  // largest s with grp_start[s] <= g
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (pp.grp_start[mid] <= g)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    seg = lo;
+    uint32_t gi = g - pp.grp_start[lo];
+    uint64_t b = (uint64_t)pp.seg_off[lo] + (uint64_t)gi * gt;
+    begin = (uint32_t)b;
+    end = (uint32_t)min((uint64_t)pp.seg_off[lo + 1], b + gt);
+    return begin < end;
+}
+
+// ============================================================== K2 histogram
+// Counting half of the radix partition (reference counterpart: the serial
+// histogram src/execute.cpp:124-132).  LDS atomics per tuple, one coalesced
+// row of F counters per group to HBM (+ F global adds for the bin totals).
+template <class Loader>
+__global__ __launch_bounds__(PT_THREADS) void k_pass_hist(Loader ld, PassParams pp) {
+    __shared__ uint32_t s_h[PT_MAXF];
+    uint32_t            seg, begin, end;
+    if (!group_range(pp, blockIdx.x, seg, begin, end)) return;
+    const uint32_t F = 1u << pp.fanout_log2, mask = F - 1u;
+    for (uint32_t d = threadIdx.x; d < F; d += PT_THREADS) s_h[d] = 0;
+    __syncthreads();
+    for (uint32_t base = begin; base < end; base += PT_TILE) {
+#pragma unroll 4
+        for (int j = 0; j < PT_ITEMS; ++j) {
+            uint32_t i = base + j * PT_THREADS + threadIdx.x;
+            uint32_t hk;
+            if (i < end && ld.key(i, hk)) atomicAdd(&s_h[(hk >> pp.shift) & mask], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t d = threadIdx.x; d < F; d += PT_THREADS) {
+        uint32_t c = s_h[d];
+        pp.group_hist[(size_t)blockIdx.x * F + d] = c;
+        if (c) atomicAdd(&pp.hist[(size_t)seg * F + d], c);
+    }
+}
+
+// ================================================================ K4 scatter
+// Scatter half of the radix partition (reference counterpart: the serial
+// scatter src/execute.cpp:175-184).  Per tile of 8192 tuples:
+//   1. every tuple takes its rank inside its digit from an LDS atomic add;
+//   2. the digit counters are scanned (wave shuffles) into LDS positions;
+//   3. per word array the tile is written to LDS in digit order, then copied out
+//      so that consecutive lanes write consecutive addresses of one digit's run
+//      (software write-combining: HBM sees contiguous runs, not 4-byte scatters).
+// The group reserved its output ranges up front with one atomic per digit.
+template <int NW, class Loader>
+__global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassParams pp, Words out) {
+    __shared__ uint32_t s_stage[PT_TILE];
+    __shared__ uint16_t s_dig[PT_TILE];
+    __shared__ uint32_t s_cnt[PT_MAXF];
+    __shared__ uint32_t s_base[PT_MAXF];
+    __shared__ uint32_t s_run[PT_MAXF];
+    __shared__ uint32_t s_wsum[PT_THREADS / 64];
+    uint32_t            seg, begin, end;
+    if (!group_range(pp, blockIdx.x, seg, begin, end)) return;
+    const uint32_t F = 1u << pp.fanout_log2, mask = F - 1u;
+
+    for (uint32_t d = threadIdx.x; d < F; d += PT_THREADS) {
+        uint32_t c = pp.group_hist[(size_t)blockIdx.x * F + d];
+        s_run[d] = c ? atomicAdd(&pp.cursor[(size_t)seg * F + d], c) : 0u;
+    }
+
+    for (uint32_t base = begin; base < end; base += PT_TILE) {
+        for (uint32_t d = threadIdx.x; d < F; d += PT_THREADS) s_cnt[d] = 0;
+        __syncthreads();
+
+        uint32_t w[PT_ITEMS][NW];
+        uint32_t dr[PT_ITEMS];  // digit << 16 | rank, 0xffffffff = no tuple
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS; ++j) {
+            uint32_t i = base + j * PT_THREADS + threadIdx.x;
+            dr[j] = 0xffffffffu;
+            if (i < end && ld.template load<NW>(i, w[j])) {
+                uint32_t d = (w[j][0] >> pp.shift) & mask;
+                uint32_t r = atomicAdd(&s_cnt[d], 1u);
+                dr[j] = (d << 16) | r;
+            }
+        }
+        __syncthreads();
+
+        // PT_MAXF == PT_THREADS: thread d scans digit d
+        uint32_t c = threadIdx.x < F ? s_cnt[threadIdx.x] : 0u;
+        uint32_t total;
+        uint32_t ex = block_excl_scan(c, s_wsum, total);
+        if (threadIdx.x < F) s_base[threadIdx.x] = ex;
+        __syncthreads();
+
+#pragma unroll
+        for (int a = 0; a < NW; ++a) {
+#pragma unroll
+            for (int j = 0; j < PT_ITEMS; ++j) {
+                if (dr[j] != 0xffffffffu) {
+                    uint32_t d = dr[j] >> 16;
+                    uint32_t pos = s_base[d] + (dr[j] & 0xffffu);
+                    s_stage[pos] = w[j][a];
+                    if (a == 0) s_dig[pos] = (uint16_t)d;
+                }
+            }
+            __syncthreads();
+            uint32_t* dst = out.w[a];
+            for (uint32_t i = threadIdx.x; i < total; i += PT_THREADS) {
+                uint32_t d = s_dig[i];
+                dst[s_run[d] + (i - s_base[d])] = s_stage[i];
+            }
+            __syncthreads();
+        }
+        for (uint32_t d = threadIdx.x; d < F; d += PT_THREADS) s_run[d] += s_cnt[d];
+        // the next iteration's s_cnt reset is done by the same thread d, and is
+        // followed by a barrier before any atomic touches it
+    }
+}
+
+// ============================================================= heavy task list
+// Probe partitions above JN_HEAVY tuples are cut into tasks so that a skewed
+// (Zipf) probe side does not serialise on one workgroup; each task rebuilds the
+// (small) build table of its partition.
+__global__ void k_heavy_tasks(const uint32_t* offR, const uint32_t* offS, uint32_t NP,
+                              uint32_t* tasks, uint32_t* n_heavy, uint32_t max_tasks) {
+    uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= NP) return;
+    uint32_t sb = offS[q], se = offS[q + 1];
+    uint32_t len = se - sb;
+    if (len <= JN_HEAVY || offR[q + 1] == offR[q]) return;
+    uint32_t nt = (len + JN_HEAVY - 1) / JN_HEAVY;
+    uint32_t b = atomicAdd(n_heavy, nt);
+    for (uint32_t t = 0; t < nt; ++t) {
+        uint32_t k = b + t;
+        if (k >= max_tasks) break;  // cannot happen: max_tasks >= 2*|S|/JN_HEAVY + 1
+        tasks[3 * k + 0] = q;
+        tasks[3 * k + 1] = sb + t * JN_HEAVY;
+        tasks[3 * k + 2] = min(se, sb + (t + 1) * JN_HEAVY);
+    }
+}
+
+// ========================================================== K5/K6 build + probe
+// Replaces the per-bucket table of the reference (src/execute.cpp:203-248):
+//   build  — linear probing in LDS, slot claimed with one LDS compare-and-swap;
+//            duplicate build keys simply occupy further slots of the same run;
+//   probe  — walk the run until the EMPTY marker, every equal key is a match
+//            (so duplicates multiply, reference :232-243);
+//   emit   — ballot/mbcnt offsets inside the wave, one global atomic per 4096
+//            probe tuples reserves the output rows; lanes of a wave then write
+//            consecutive rows of each output stream (coalesced).
+// Slot index uses hash bits ABOVE the radix bits (the reference reuses the low
+// bits for both, SURVEY.md §3.2 — not copied).  EMPTY is a word whose radix bits
+// differ from the partition's, so it cannot collide with a stored hashed key.
+// A build partition larger than JN_RMAX is processed in table-sized chunks
+// (block nested loop), which keeps any duplicate-heavy input correct.
+template <int KW, int CWR, int CWS>
+__global__ __launch_bounds__(JN_THREADS) void k_join(JoinParams jp) {
+    constexpr int      RW = KW + CWR;  // LDS table arrays (one per word)
+    __shared__ uint32_t t_w[RW][JN_CAP];
+    __shared__ uint32_t s_wtot[JN_THREADS / 64];
+    __shared__ unsigned long long s_obase;
+
+    uint32_t q, sbeg, send;
+    if (jp.heavy_pass) {
+        if (blockIdx.x >= *jp.n_heavy) return;
+        q = jp.heavy_tasks[3 * blockIdx.x + 0];
+        sbeg = jp.heavy_tasks[3 * blockIdx.x + 1];
+        send = jp.heavy_tasks[3 * blockIdx.x + 2];
+    } else {
+        q = blockIdx.x;
+        if (q >= jp.NP) return;
+        sbeg = jp.offS[q];
+        send = jp.offS[q + 1];
+        if (send - sbeg > JN_HEAVY) return;  // split into tasks by k_heavy_tasks
+    }
+    const uint32_t rbeg = jp.offR[q], rend = jp.offR[q + 1];
+    if (rbeg == rend || sbeg == send) return;
+
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    const uint32_t rmask = (jp.radix_bits >= 32) ? 0xffffffffu : ((1u << jp.radix_bits) - 1u);
+    const uint32_t EMPTY = (jp.R.w[0][rbeg] & rmask) ^ 1u;
+    constexpr uint32_t SMASK = JN_CAP - 1;
+
+    for (uint32_t rc = rbeg; rc < rend; rc += JN_RMAX) {
+        const uint32_t rn = min((uint32_t)JN_RMAX, rend - rc);
+        for (uint32_t i = threadIdx.x; i < JN_CAP; i += JN_THREADS) t_w[0][i] = EMPTY;
+        __syncthreads();
+        // ---- build
+        for (uint32_t i = threadIdx.x; i < rn; i += JN_THREADS) {
+            uint32_t rw[RW];
+#pragma unroll
+            for (int a = 0; a < RW; ++a) rw[a] = jp.R.w[a][rc + i];
+            uint32_t slot = (rw[0] >> jp.radix_bits) & SMASK;
+            while (true) {
+                uint32_t old = atomicCAS(&t_w[0][slot], EMPTY, rw[0]);
+                if (old == EMPTY) {
+#pragma unroll
+                    for (int a = 1; a < RW; ++a) t_w[a][slot] = rw[a];
+                    break;
+                }
+                slot = (slot + 1) & SMASK;
+            }
+        }
+        __syncthreads();
+        // ---- probe, JN_SUB tuples at a time
+        for (uint32_t sc = sbeg; sc < send; sc += JN_SUB) {
+            const uint32_t sn = min((uint32_t)JN_SUB, send - sc);
+            uint32_t       sw[JN_SPT][KW + CWS];
+            uint32_t       m[JN_SPT], f[JN_SPT];
+#pragma unroll
+            for (int j = 0; j < JN_SPT; ++j) {
+                uint32_t i = j * JN_THREADS + threadIdx.x;
+                m[j] = 0;
+                f[j] = 0;
+                if (i < sn) {
+#pragma unroll
+                    for (int a = 0; a < KW + CWS; ++a) sw[j][a] = jp.S.w[a][sc + i];
+                } else {
+#pragma unroll
+                    for (int a = 0; a < KW + CWS; ++a) sw[j][a] = 0;
+                }
+            }
+            // count matches, remember the first matching slot
+#pragma unroll
+            for (int j = 0; j < JN_SPT; ++j) {
+                uint32_t i = j * JN_THREADS + threadIdx.x;
+                if (i < sn) {
+                    uint32_t slot = (sw[j][0] >> jp.radix_bits) & SMASK;
+                    while (true) {
+                        uint32_t k = t_w[0][slot];
+                        if (k == EMPTY) break;
+                        bool eq = k == sw[j][0];
+                        if (KW == 2) eq = eq && t_w[KW - 1][slot] == sw[j][KW - 1];
+                        if (eq) {
+                            if (m[j] == 0) f[j] = slot;
+                            ++m[j];
+                        }
+                        slot = (slot + 1) & SMASK;
+                    }
+                }
+            }
+            // offsets inside the wave: ballot + mbcnt when every lane has <= 1 match
+            // (the PK-FK case), shuffle scan otherwise
+            uint32_t pre[JN_SPT];
+            uint32_t wave_total = 0;
+#pragma unroll
+            for (int j = 0; j < JN_SPT; ++j) {
+                uint32_t tot;
+                if (__ballot(m[j] > 1) == 0) {
+                    uint64_t mk = __ballot(m[j] == 1);
+                    pre[j] = lane_prefix(mk);
+                    tot = (uint32_t)__popcll(mk);
+                } else {
+                    uint32_t incl = m[j];
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) {
+                        uint32_t t = __shfl_up(incl, off);
+                        if (lane >= (uint32_t)off) incl += t;
+                    }
+                    pre[j] = incl - m[j];
+                    tot = __shfl(incl, 63);
+                }
+                pre[j] += wave_total;
+                wave_total += tot;
+            }
+            if (lane == 0) s_wtot[wid] = wave_total;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t tot = 0;
+                for (int k = 0; k < JN_THREADS / 64; ++k) tot += s_wtot[k];
+                s_obase = tot ? atomicAdd(jp.out_cursor, (unsigned long long)tot) : 0ull;
+            }
+            __syncthreads();
+            uint64_t obase = s_obase;
+            uint32_t block_total = 0;
+            for (uint32_t k = 0; k < JN_THREADS / 64; ++k) {
+                uint32_t t = s_wtot[k];
+                if (k < wid) obase += t;
+                block_total += t;
+            }
+            // rows beyond the stream capacity are counted but not written; the host
+            // re-runs the join with exact-size buffers (out_cursor = rows needed)
+            const bool fits = s_obase + block_total <= jp.out_cap;
+            if (fits) {
+#pragma unroll
+                for (int j = 0; j < JN_SPT; ++j) {
+                    if (m[j] == 0) continue;
+                    uint64_t row = obase + pre[j];
+                    uint32_t klo, khi = 0;
+                    if (KW == 1) {
+                        klo = unfmix32(sw[j][0]);
+                    } else {
+                        uint64_t k = unfmix64((uint64_t)sw[j][0] | ((uint64_t)sw[j][KW - 1] << 32));
+                        klo = (uint32_t)k;
+                        khi = (uint32_t)(k >> 32);
+                    }
+                    uint32_t slot = f[j];
+                    uint32_t left = m[j];
+                    while (left) {
+                        bool eq = t_w[0][slot] == sw[j][0];
+                        if (KW == 2) eq = eq && t_w[KW - 1][slot] == sw[j][KW - 1];
+                        if (eq) {
+                            stream_store(jp.key, row, klo, khi);
+                            if constexpr (CWR >= 1)
+                                stream_store(jp.bc, row, t_w[KW][slot],
+                                             CWR == 2 ? t_w[KW + CWR - 1][slot] : 0u);
+                            if constexpr (CWS >= 1)
+                                stream_store(jp.pc, row, sw[j][KW],
+                                             CWS == 2 ? sw[j][KW + CWS - 1] : 0u);
+                            ++row;
+                            --left;
+                        }
+                        slot = (slot + 1) & SMASK;
+                    }
+                }
+            }
+            __syncthreads();  // s_wtot / s_obase are reused by the next sub-chunk
+        }
+        __syncthreads();  // table is cleared for the next build chunk
+    }
+}
+
+// ================================================================== K7 gather
+// Late materialisation: out[i] = column[idx[i]] (reference counterpart: the
+// per-row `out.push_back(lrow[ci])`, src/execute.cpp:236-242).
+template <int WIDTH>
+__global__ __launch_bounds__(256) void k_gather(ColRef src, const uint32_t* idx, uint64_t n,
+                                                OutStream dst, uint8_t* dst_valid) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t r = idx ? idx[i] : (uint32_t)i;
+    if (WIDTH == 4) {
+        stream_store(dst, i, col_load32(src, r), 0u);
+    } else {
+        uint64_t v = col_load64(src, r);
+        stream_store(dst, i, (uint32_t)v, (uint32_t)(v >> 32));
+    }
+    if (dst_valid) dst_valid[i] = src.valid ? src.valid[r] : (uint8_t)1;
+}
+
+// =========================================================== K8 page finishing
+// Headers + all-ones validity bitmaps of result pages whose values were written
+// in place by the probe / gather kernels (page layout: reference
+// src/build_table.cpp:472-481).
+__global__ __launch_bounds__(256) void k_finish_pages(uint8_t* pages, uint64_t n_rows,
+                                                      uint32_t rows_full) {
+    uint8_t*       page = pages + (size_t)blockIdx.x * PAGE_BYTES;
+    const uint64_t first = (uint64_t)blockIdx.x * rows_full;
+    const uint32_t nr = (uint32_t)min((uint64_t)rows_full, n_rows - first);
+    const uint32_t nb = (nr + 7) / 8;
+    if (threadIdx.x == 0) {
+        reinterpret_cast<uint16_t*>(page)[0] = (uint16_t)nr;
+        reinterpret_cast<uint16_t*>(page)[1] = (uint16_t)nr;
+    }
+    uint8_t* bm = page + PAGE_BYTES - nb;
+    for (uint32_t k = threadIdx.x; k < nb; k += blockDim.x) {
+        uint32_t bits = nr - k * 8u;
+        bm[k] = bits >= 8 ? 0xff : (uint8_t)((1u << bits) - 1u);
+    }
+}
+
+// Result pages of a column that carries NULLs: a fixed rows_full rows per page
+// (any fill that satisfies the layout decodes to the same rows), values packed
+// densely in row order, bitmap at the tail.
+template <int WIDTH>
+__global__ __launch_bounds__(256) void k_encode_nullable(const uint8_t* values, const uint8_t* valid,
+                                                         uint64_t n_rows, uint8_t* pages) {
+    __shared__ uint32_t s_w[4];
+    constexpr uint32_t  RF = WIDTH == 4 ? ROWS32 : ROWS64;
+    uint8_t*            page = pages + (size_t)blockIdx.x * PAGE_BYTES;
+    const uint64_t      first = (uint64_t)blockIdx.x * RF;
+    const uint32_t      nr = (uint32_t)min((uint64_t)RF, n_rows - first);
+    const uint32_t      nb = (nr + 7) / 8;
+    uint8_t*            out_vals = page + (WIDTH == 4 ? HDR32 : HDR64);
+    uint8_t*            bm = page + PAGE_BYTES - nb;
+    const uint32_t      lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    uint32_t            running = 0;
+    for (uint32_t base = 0; base < nr; base += 256) {
+        uint32_t i = base + threadIdx.x;
+        bool     bit = i < nr ? valid[first + i] != 0 : false;
+        uint64_t mask = __ballot(bit);
+        uint32_t pre = lane_prefix(mask);
+        if (lane == 0) s_w[wid] = (uint32_t)__popcll(mask);
+        __syncthreads();
+        uint32_t wpre = 0, tot = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            uint32_t c = s_w[k];
+            if (k < wid) wpre += c;
+            tot += c;
+        }
+        if (bit) {
+            uint32_t vi = running + wpre + pre;
+            if (WIDTH == 4)
+                reinterpret_cast<uint32_t*>(out_vals)[vi] =
+                    reinterpret_cast<const uint32_t*>(values)[first + i];
+            else
+                reinterpret_cast<uint64_t*>(out_vals)[vi] =
+                    reinterpret_cast<const uint64_t*>(values)[first + i];
+        }
+        // bitmap bytes of this 256-row slab: the wave's ballot holds 8 of them
+        if (lane < 8) {
+            uint32_t byte_idx = (base >> 3) + wid * 8u + lane;
+            if (byte_idx < nb) bm[byte_idx] = (uint8_t)(mask >> (lane * 8u));
+        }
+        running += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        reinterpret_cast<uint16_t*>(page)[0] = (uint16_t)nr;
+        reinterpret_cast<uint16_t*>(page)[1] = (uint16_t)running;
+    }
+}
+
+__global__ void k_unhash32(uint32_t* keys, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = unfmix32(keys[i]);
+}
+
+// ================================================================== launchers
+#define RJ_KLAUNCH(L, NAME, KERNEL, GRID, BLOCK, ...)                         \
+    do {                                                                      \
+        if ((L).begin) (L).begin((L).self, NAME);                             \
+        hipLaunchKernelGGL(KERNEL, dim3(GRID), dim3(BLOCK), 0, (L).stream, __VA_ARGS__); \
+        if ((L).end) (L).end((L).self);                                       \
+    } while (0)
+
+void launch_page_headers(const Launch& L, const uint8_t* pages, uint32_t n_pages, uint32_t rows_full,
+                         uint32_t* page_rows, unsigned long long* flags) {
+    if (!n_pages) return;
+    RJ_KLAUNCH(L, "page_headers", k_page_headers, (n_pages + 255) / 256, 256, pages, n_pages,
+               rows_full, page_rows, flags);
+}
+
+void launch_decode_pages(const Launch& L, const uint8_t* pages, uint32_t n_pages, int width,
+                         const uint32_t* row_base, uint64_t num_rows, uint8_t* values,
+                         uint8_t* valid) {
+    if (!n_pages) return;
+    if (width == 4)
+        RJ_KLAUNCH(L, "decode_pages", (k_decode_pages<4>), n_pages, 256, pages, row_base, num_rows,
+                   values, valid);
+    else
+        RJ_KLAUNCH(L, "decode_pages", (k_decode_pages<8>), n_pages, 256, pages, row_base, num_rows,
+                   values, valid);
+}
+
+void launch_scan_bins(const Launch& L, const uint32_t* in, uint32_t n, uint32_t* off,
+                      uint32_t* cursor) {
+    RJ_KLAUNCH(L, "scan_bins", (k_scan_bins<0>), 1, 1024, in, n, 1u, off, cursor);
+}
+
+void launch_group_table(const Launch& L, const uint32_t* seg_off, uint32_t nseg,
+                        uint32_t group_tuples, uint32_t* grp_start) {
+    RJ_KLAUNCH(L, "group_table", (k_scan_bins<1>), 1, 1024, seg_off, nseg, group_tuples, grp_start,
+               (uint32_t*)nullptr);
+}
+
+void launch_pass_hist_src(const Launch& L, const TupleSrc& src, int key_words, const PassParams& pp,
+                          uint32_t n_groups) {
+    if (!n_groups) return;
+    if (key_words == 1) {
+        SrcLoader<1, 0> ld{src};
+        RJ_KLAUNCH(L, "pass1_hist", (k_pass_hist<SrcLoader<1, 0>>), n_groups, PT_THREADS, ld, pp);
+    } else {
+        SrcLoader<2, 0> ld{src};
+        RJ_KLAUNCH(L, "pass1_hist", (k_pass_hist<SrcLoader<2, 0>>), n_groups, PT_THREADS, ld, pp);
+    }
+}
+
+template <int KW, int CW>
+static void scatter_src_t(const Launch& L, const TupleSrc& src, const PassParams& pp,
+                          uint32_t n_groups, const Words& out) {
+    SrcLoader<KW, CW> ld{src};
+    RJ_KLAUNCH(L, "pass1_scatter", (k_pass_scatter<KW + CW, SrcLoader<KW, CW>>), n_groups,
+               PT_THREADS, ld, pp, out);
+}
+
+void launch_pass_scatter_src(const Launch& L, const TupleSrc& src, int key_words, int carry_words,
+                             const PassParams& pp, uint32_t n_groups, const Words& out) {
+    if (!n_groups) return;
+    switch (key_words * 10 + carry_words) {
+    case 10: scatter_src_t<1, 0>(L, src, pp, n_groups, out); break;
+    case 11: scatter_src_t<1, 1>(L, src, pp, n_groups, out); break;
+    case 12: scatter_src_t<1, 2>(L, src, pp, n_groups, out); break;
+    case 20: scatter_src_t<2, 0>(L, src, pp, n_groups, out); break;
+    case 21: scatter_src_t<2, 1>(L, src, pp, n_groups, out); break;
+    case 22: scatter_src_t<2, 2>(L, src, pp, n_groups, out); break;
+    default: break;
+    }
+}
+
+void launch_pass_hist_dense(const Launch& L, const Words& in, const PassParams& pp,
+                            uint32_t n_groups) {
+    if (!n_groups) return;
+    DenseLoader ld{in};
+    RJ_KLAUNCH(L, "pass2_hist", (k_pass_hist<DenseLoader>), n_groups, PT_THREADS, ld, pp);
+}
+
+void launch_pass_scatter_dense(const Launch& L, const Words& in, int n_words, const PassParams& pp,
+                               uint32_t n_groups, const Words& out) {
+    if (!n_groups) return;
+    DenseLoader ld{in};
+    switch (n_words) {
+    case 1:
+        RJ_KLAUNCH(L, "pass2_scatter", (k_pass_scatter<1, DenseLoader>), n_groups, PT_THREADS, ld,
+                   pp, out);
+        break;
+    case 2:
+        RJ_KLAUNCH(L, "pass2_scatter", (k_pass_scatter<2, DenseLoader>), n_groups, PT_THREADS, ld,
+                   pp, out);
+        break;
+    case 3:
+        RJ_KLAUNCH(L, "pass2_scatter", (k_pass_scatter<3, DenseLoader>), n_groups, PT_THREADS, ld,
+                   pp, out);
+        break;
+    case 4:
+        RJ_KLAUNCH(L, "pass2_scatter", (k_pass_scatter<4, DenseLoader>), n_groups, PT_THREADS, ld,
+                   pp, out);
+        break;
+    default: break;
+    }
+}
+
+void launch_heavy_tasks(const Launch& L, const uint32_t* offR, const uint32_t* offS, uint32_t NP,
+                        uint32_t* tasks, uint32_t* n_heavy, uint32_t max_tasks) {
+    RJ_KLAUNCH(L, "heavy_tasks", k_heavy_tasks, (NP + 255) / 256, 256, offR, offS, NP, tasks,
+               n_heavy, max_tasks);
+}
+
+template <int KW, int CWR, int CWS>
+static void join_t(const Launch& L, const JoinParams& jp, uint32_t grid) {
+    RJ_KLAUNCH(L, jp.heavy_pass ? "join_heavy" : "join_build_probe", (k_join<KW, CWR, CWS>), grid,
+               JN_THREADS, jp);
+}
+
+void launch_join(const Launch& L, int key_words, int cw_build, int cw_probe, const JoinParams& jp,
+                 uint32_t grid) {
+    if (!grid) return;
+    switch (key_words * 100 + cw_build * 10 + cw_probe) {
+    case 100: join_t<1, 0, 0>(L, jp, grid); break;
+    case 101: join_t<1, 0, 1>(L, jp, grid); break;
+    case 102: join_t<1, 0, 2>(L, jp, grid); break;
+    case 110: join_t<1, 1, 0>(L, jp, grid); break;
+    case 111: join_t<1, 1, 1>(L, jp, grid); break;
+    case 112: join_t<1, 1, 2>(L, jp, grid); break;
+    case 120: join_t<1, 2, 0>(L, jp, grid); break;
+    case 121: join_t<1, 2, 1>(L, jp, grid); break;
+    case 122: join_t<1, 2, 2>(L, jp, grid); break;
+    case 200: join_t<2, 0, 0>(L, jp, grid); break;
+    case 201: join_t<2, 0, 1>(L, jp, grid); break;
+    case 202: join_t<2, 0, 2>(L, jp, grid); break;
+    case 210: join_t<2, 1, 0>(L, jp, grid); break;
+    case 211: join_t<2, 1, 1>(L, jp, grid); break;
+    case 212: join_t<2, 1, 2>(L, jp, grid); break;
+    case 220: join_t<2, 2, 0>(L, jp, grid); break;
+    case 221: join_t<2, 2, 1>(L, jp, grid); break;
+    case 222: join_t<2, 2, 2>(L, jp, grid); break;
+    default: break;
+    }
+}
+
+void launch_gather(const Launch& L, const ColRef& src, const uint32_t* idx, uint64_t n,
+                   const OutStream& dst, uint8_t* dst_valid) {
+    if (!n) return;
+    uint32_t grid = (uint32_t)((n + 255) / 256);
+    if (src.width == 4)
+        RJ_KLAUNCH(L, "gather", (k_gather<4>), grid, 256, src, idx, n, dst, dst_valid);
+    else
+        RJ_KLAUNCH(L, "gather", (k_gather<8>), grid, 256, src, idx, n, dst, dst_valid);
+}
+
+void launch_finish_pages(const Launch& L, uint8_t* pages, uint64_t n_rows, int width) {
+    if (!n_rows) return;
+    uint32_t rf = width == 4 ? ROWS32 : ROWS64;
+    uint32_t np = (uint32_t)((n_rows + rf - 1) / rf);
+    RJ_KLAUNCH(L, "finish_pages", k_finish_pages, np, 256, pages, n_rows, rf);
+}
+
+void launch_encode_nullable(const Launch& L, const uint8_t* values, const uint8_t* valid,
+                            uint64_t n_rows, int width, uint8_t* pages) {
+    if (!n_rows) return;
+    uint32_t rf = width == 4 ? ROWS32 : ROWS64;
+    uint32_t np = (uint32_t)((n_rows + rf - 1) / rf);
+    if (width == 4)
+        RJ_KLAUNCH(L, "encode_nullable", (k_encode_nullable<4>), np, 256, values, valid, n_rows,
+                   pages);
+    else
+        RJ_KLAUNCH(L, "encode_nullable", (k_encode_nullable<8>), np, 256, values, valid, n_rows,
+                   pages);
+}
+
+void launch_unhash32(const Launch& L, uint32_t* keys, uint64_t n) {
+    if (!n) return;
+    RJ_KLAUNCH(L, "unhash", k_unhash32, (uint32_t)((n + 255) / 256), 256, keys, n);
+}
+
+}  // namespace rj

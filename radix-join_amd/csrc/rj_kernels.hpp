@@ -1,0 +1,62 @@
+// rj_kernels.hpp — host-callable launchers of the gfx950 kernels (rj_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rj_device.hpp"
+
+namespace rj {
+
+// Stream + optional per-kernel HIP-event timing.  Implemented in rj_context.hip.
+struct Launch {
+    hipStream_t stream;
+    void (*begin)(void* self, const char* name);
+    void (*end)(void* self);
+    void* self;
+};
+
+// ---- page metadata / decode (replaces Table::from_columnar, reference
+//      src/build_table.cpp:312-436, for fixed-width columns)
+// flags[0] = #pages breaking the "regular" shape, flags[1..2] = total rows (u64)
+void launch_page_headers(const Launch& L, const uint8_t* pages, uint32_t n_pages, uint32_t rows_full,
+                         uint32_t* page_rows, unsigned long long* flags);
+void launch_decode_pages(const Launch& L, const uint8_t* pages, uint32_t n_pages, int width,
+                         const uint32_t* row_base, uint64_t num_rows, uint8_t* values,
+                         uint8_t* valid);
+
+// ---- small single-workgroup scans
+// off[i] = sum_{j<i} in[j], off[n] = total; cursor (optional) = copy of off[0..n)
+void launch_scan_bins(const Launch& L, const uint32_t* in, uint32_t n, uint32_t* off,
+                      uint32_t* cursor);
+// grp_start[s] = sum_{t<s} ceil(len_t / group_tuples) over segments (seg_off[nseg+1])
+void launch_group_table(const Launch& L, const uint32_t* seg_off, uint32_t nseg,
+                        uint32_t group_tuples, uint32_t* grp_start);
+
+// ---- radix partition pass (replaces the ≤128-way hash partition of row indices,
+//      reference src/execute.cpp:124-184)
+// Source pass: tuples are formed from columns (page decode fused in).
+void launch_pass_hist_src(const Launch& L, const TupleSrc& src, int key_words, const PassParams& pp,
+                          uint32_t n_groups);
+void launch_pass_scatter_src(const Launch& L, const TupleSrc& src, int key_words, int carry_words,
+                             const PassParams& pp, uint32_t n_groups, const Words& out);
+// Dense pass: re-partition every segment of already partitioned word arrays.
+void launch_pass_hist_dense(const Launch& L, const Words& in, const PassParams& pp,
+                            uint32_t n_groups);
+void launch_pass_scatter_dense(const Launch& L, const Words& in, int n_words, const PassParams& pp,
+                               uint32_t n_groups, const Words& out);
+
+// ---- build + probe (replaces reference src/execute.cpp:196-249)
+void launch_heavy_tasks(const Launch& L, const uint32_t* offR, const uint32_t* offS, uint32_t NP,
+                        uint32_t* tasks, uint32_t* n_heavy, uint32_t max_tasks);
+void launch_join(const Launch& L, int key_words, int cw_build, int cw_probe, const JoinParams& jp,
+                 uint32_t grid);
+
+// ---- materialise (replaces the per-row output copy, reference src/execute.cpp:236-242,
+//      and Table::to_columnar, src/build_table.cpp:456-594)
+void launch_gather(const Launch& L, const ColRef& src, const uint32_t* idx, uint64_t n,
+                   const OutStream& dst, uint8_t* dst_valid);
+void launch_finish_pages(const Launch& L, uint8_t* pages, uint64_t n_rows, int width);
+void launch_encode_nullable(const Launch& L, const uint8_t* values, const uint8_t* valid,
+                            uint64_t n_rows, int width, uint8_t* pages);
+void launch_unhash32(const Launch& L, uint32_t* keys, uint64_t n);
+
+}  // namespace rj

@@ -1,0 +1,336 @@
+"""ctypes binding of librj.so — the C-ABI in include/rj.h.
+
+This is the same call sequence the C++ shim (radix-join_amd/host/contest_execute.cpp)
+performs behind ``Contest::execute``: flatten the Plan, rj_execute, copy the result
+pages out.  There is NO CPU fallback here: if the HIP library is missing or there is
+no GPU, construction fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import pages as pg
+from . import plan as pl
+
+PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(PKG_DIR, "librj.so")
+
+RJ_EXEC_KEEP_ON_DEVICE = 1
+
+
+class rj_config(C.Structure):
+    _fields_ = [
+        ("device", C.c_int32),
+        ("profile", C.c_int32),
+        ("stream", C.c_void_p),
+        ("radix_bits", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("reserved1", C.c_uint64),
+    ]
+
+
+class rj_tuples(C.Structure):
+    _fields_ = [
+        ("n", C.c_uint64),
+        ("key", C.c_void_p),
+        ("carry", C.c_void_p),
+        ("hashed", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+class rj_kernel_stat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
+
+
+class rj_device_info(C.Structure):
+    _fields_ = [
+        ("name", C.c_char * 128),
+        ("arch", C.c_char * 64),
+        ("compute_units", C.c_int32),
+        ("wavefront", C.c_int32),
+        ("hbm_bytes", C.c_uint64),
+        ("lds_per_cu", C.c_uint64),
+    ]
+
+
+# every symbol include/rj.h declares (tests/test_capi_symbols.py checks the export list)
+EXPORTS = [
+    "rj_abi_version",
+    "rj_context_create",
+    "rj_context_destroy",
+    "rj_last_error",
+    "rj_table_upload",
+    "rj_table_adopt_device",
+    "rj_table_release",
+    "rj_execute",
+    "rj_execute_resident",
+    "rj_result_num_rows",
+    "rj_result_num_cols",
+    "rj_result_col_type",
+    "rj_result_col_pages",
+    "rj_result_copy_pages",
+    "rj_result_device_pages",
+    "rj_result_free",
+    "rj_shard_partition",
+    "rj_join_tuples",
+    "rj_profile_read",
+    "rj_profile_reset",
+    "rj_device_query",
+]
+
+_LIB = None
+
+
+class RjError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"librj error {code}: {msg}")
+        self.code = code
+        self.message = msg
+
+
+def load():
+    """Load librj.so (built in-tree by ``__graft_entry__.build()`` / csrc/Makefile)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+            "There is no CPU fallback."
+        )
+    L = C.CDLL(LIB_PATH)
+    vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int32
+    L.rj_abi_version.restype = C.c_int
+    L.rj_context_create.argtypes = [C.POINTER(vp), C.POINTER(rj_config)]
+    L.rj_context_create.restype = C.c_int
+    L.rj_context_destroy.argtypes = [vp]
+    L.rj_context_destroy.restype = None
+    L.rj_last_error.argtypes = [vp]
+    L.rj_last_error.restype = C.c_char_p
+    L.rj_table_upload.argtypes = [vp, C.POINTER(pl.rj_input), C.POINTER(vp)]
+    L.rj_table_upload.restype = C.c_int
+    L.rj_table_adopt_device.argtypes = [vp, u64, u64, C.POINTER(i32), C.POINTER(vp), C.POINTER(u64), C.POINTER(vp)]
+    L.rj_table_adopt_device.restype = C.c_int
+    L.rj_table_release.argtypes = [vp, vp]
+    L.rj_table_release.restype = None
+    L.rj_execute.argtypes = [vp, C.POINTER(pl.rj_plan), C.POINTER(vp)]
+    L.rj_execute.restype = C.c_int
+    L.rj_execute_resident.argtypes = [vp, C.POINTER(pl.rj_plan), C.POINTER(vp), u64, i32, C.POINTER(vp)]
+    L.rj_execute_resident.restype = C.c_int
+    L.rj_result_num_rows.argtypes = [vp]
+    L.rj_result_num_rows.restype = u64
+    L.rj_result_num_cols.argtypes = [vp]
+    L.rj_result_num_cols.restype = u64
+    L.rj_result_col_type.argtypes = [vp, u64]
+    L.rj_result_col_type.restype = i32
+    L.rj_result_col_pages.argtypes = [vp, u64]
+    L.rj_result_col_pages.restype = u64
+    L.rj_result_copy_pages.argtypes = [vp, u64, C.POINTER(vp), u64]
+    L.rj_result_copy_pages.restype = C.c_int
+    L.rj_result_device_pages.argtypes = [vp, u64]
+    L.rj_result_device_pages.restype = vp
+    L.rj_result_free.argtypes = [vp]
+    L.rj_result_free.restype = None
+    L.rj_shard_partition.argtypes = [vp, vp, u64, u64, C.c_uint32, C.POINTER(rj_tuples), C.POINTER(u64)]
+    L.rj_shard_partition.restype = C.c_int
+    L.rj_join_tuples.argtypes = [vp, C.POINTER(rj_tuples), C.POINTER(rj_tuples), C.c_uint32, i32, C.POINTER(vp)]
+    L.rj_join_tuples.restype = C.c_int
+    L.rj_profile_read.argtypes = [vp, C.POINTER(rj_kernel_stat), u64, C.POINTER(u64)]
+    L.rj_profile_read.restype = C.c_int
+    L.rj_profile_reset.argtypes = [vp]
+    L.rj_profile_reset.restype = None
+    L.rj_device_query.argtypes = [vp, C.POINTER(rj_device_info)]
+    L.rj_device_query.restype = C.c_int
+    _LIB = L
+    return L
+
+
+class Result:
+    """rj_result*: the ColumnarTable ``execute`` returns (pages still in HBM)."""
+
+    def __init__(self, ctx: "Context", handle):
+        self.ctx, self.h = ctx, handle
+
+    @property
+    def num_rows(self):
+        return self.ctx.L.rj_result_num_rows(self.h)
+
+    @property
+    def num_cols(self):
+        return self.ctx.L.rj_result_num_cols(self.h)
+
+    def col_type(self, c):
+        return self.ctx.L.rj_result_col_type(self.h, c)
+
+    def col_pages(self, c):
+        return self.ctx.L.rj_result_col_pages(self.h, c)
+
+    def device_pages(self, c):
+        return self.ctx.L.rj_result_device_pages(self.h, c)
+
+    def to_table(self) -> pl.ColumnarTable:
+        """Copy every column into host pages (what the shim does into ``new Page``s)."""
+        L = self.ctx.L
+        t = pl.ColumnarTable(self.num_rows, [])
+        for c in range(self.num_cols):
+            n = self.col_pages(c)
+            pages = np.zeros((n, pg.PAGE_SIZE), dtype=np.uint8)
+            if n:
+                ptrs = (C.c_void_p * n)()
+                base = pages.ctypes.data
+                for i in range(n):
+                    ptrs[i] = base + i * pg.PAGE_SIZE
+                self.ctx._check(L.rj_result_copy_pages(self.h, c, ptrs, n))
+            t.columns.append(pl.Column(self.col_type(c), pages))
+        return t
+
+    def free(self):
+        if self.h:
+            self.ctx.L.rj_result_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Table:
+    """rj_table*: a device-resident ColumnarTable."""
+
+    def __init__(self, ctx: "Context", handle, keep=None):
+        self.ctx, self.h, self.keep = ctx, handle, keep
+
+    def release(self):
+        if self.h:
+            self.ctx.L.rj_table_release(self.ctx.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+class Context:
+    """rj_context*: ``Contest::build_context()`` / ``destroy_context()``."""
+
+    def __init__(self, device=-1, profile=False, stream=None, radix_bits=0):
+        self.L = load()
+        cfg = rj_config(device, 1 if profile else 0, stream, radix_bits, 0, 0)
+        h = C.c_void_p()
+        rc = self.L.rj_context_create(C.byref(h), C.byref(cfg))
+        if rc != 0:
+            raise RjError(rc, (self.L.rj_last_error(None) or b"").decode())
+        self.h = h
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RjError(rc, (self.L.rj_last_error(self.h) or b"").decode())
+
+    def destroy(self):
+        if getattr(self, "h", None):
+            self.L.rj_context_destroy(self.h)
+            self.h = None
+
+    # -- tables
+    def upload(self, t: pl.ColumnarTable) -> Table:
+        keep: list = []
+        inp = pl.input_to_c(t, keep)
+        h = C.c_void_p()
+        self._check(self.L.rj_table_upload(self.h, C.byref(inp), C.byref(h)))
+        return Table(self, h)
+
+    def adopt_device(self, num_rows, types, dev_ptrs, n_pages, keep=None) -> Table:
+        n = len(types)
+        ct = (C.c_int32 * n)(*types)
+        cp = (C.c_void_p * n)(*dev_ptrs)
+        cn = (C.c_uint64 * n)(*n_pages)
+        h = C.c_void_p()
+        self._check(self.L.rj_table_adopt_device(self.h, num_rows, n, ct, cp, cn, C.byref(h)))
+        return Table(self, h, keep)
+
+    # -- execute
+    def execute(self, plan: pl.Plan) -> pl.ColumnarTable:
+        """``Contest::execute(plan, ctx)``: host pages in, host pages out."""
+        cplan, keep = pl.plan_to_c(plan)
+        out = C.c_void_p()
+        self._check(self.L.rj_execute(self.h, C.byref(cplan), C.byref(out)))
+        r = Result(self, out)
+        try:
+            return r.to_table()
+        finally:
+            r.free()
+            del keep
+
+    def execute_resident(self, plan: pl.Plan, tables, keep_on_device=True) -> Result:
+        cplan, keep = pl.plan_to_c(plan, with_inputs=False)
+        hs = (C.c_void_p * max(1, len(tables)))(*[t.h for t in tables])
+        out = C.c_void_p()
+        flags = RJ_EXEC_KEEP_ON_DEVICE if keep_on_device else 0
+        self._check(self.L.rj_execute_resident(self.h, C.byref(cplan), hs, len(tables), flags, C.byref(out)))
+        del keep
+        return Result(self, out)
+
+    # -- sharded path
+    def shard_partition(self, table: Table, key_col, carry_col, n_ranks, key_ptr, carry_ptr):
+        """Stage A into caller-owned device buffers (capacity = table rows)."""
+        tup = rj_tuples(0, key_ptr, carry_ptr, 0, 0)
+        counts = (C.c_uint64 * n_ranks)()
+        self._check(self.L.rj_shard_partition(self.h, table.h, key_col, carry_col, n_ranks, C.byref(tup), counts))
+        return int(tup.n), [int(c) for c in counts]
+
+    def join_tuples(self, build, probe, skip_rank_bits=0, hashed=True) -> Result:
+        """Stage B: build/probe = (n, key_ptr, carry_ptr) in HBM."""
+        build = rj_tuples(build[0], build[1], build[2], 1 if hashed else 0, 0)
+        probe = rj_tuples(probe[0], probe[1], probe[2], 1 if hashed else 0, 0)
+        out = C.c_void_p()
+        self._check(self.L.rj_join_tuples(self.h, C.byref(build), C.byref(probe), skip_rank_bits, RJ_EXEC_KEEP_ON_DEVICE, C.byref(out)))
+        return Result(self, out)
+
+    # -- profiling
+    def profile(self):
+        n = C.c_uint64()
+        buf = (rj_kernel_stat * 64)()
+        self._check(self.L.rj_profile_read(self.h, buf, 64, C.byref(n)))
+        return [
+            {"name": buf[i].name.decode(), "launches": int(buf[i].launches), "total_ms": float(buf[i].total_ms)}
+            for i in range(min(n.value, 64))
+        ]
+
+    def profile_reset(self):
+        self.L.rj_profile_reset(self.h)
+
+    def device_info(self):
+        d = rj_device_info()
+        self._check(self.L.rj_device_query(self.h, C.byref(d)))
+        return {
+            "name": d.name.decode(),
+            "arch": d.arch.decode(),
+            "compute_units": d.compute_units,
+            "wavefront": d.wavefront,
+            "hbm_bytes": int(d.hbm_bytes),
+            "lds_per_cu": int(d.lds_per_cu),
+        }
+
+
+# ---------------------------------------------------------------- reference API --
+def build_context(**kw):
+    """``Contest::build_context()`` (reference src/execute.cpp:326-328)."""
+    return Context(**kw)
+
+
+def destroy_context(ctx: Context):
+    """``Contest::destroy_context()`` (reference src/execute.cpp:330)."""
+    ctx.destroy()
+
+
+def execute(plan: pl.Plan, ctx: Context) -> pl.ColumnarTable:
+    """``Contest::execute(const Plan&, void*)`` (reference src/execute.cpp:316-324)."""
+    return ctx.execute(plan)
