@@ -92,6 +92,28 @@ class RjError(RuntimeError):
         self.message = msg
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64 /
+    libhsa-runtime64 (same soname ``libamdhip64.so.7`` as /opt/rocm's); if librj.so pulled
+    in /opt/rocm's copy first and torch then loaded its own, two HSA runtimes would fight
+    over the device ("No HIP GPUs are available").  Loading torch's copy first — by path,
+    without importing torch — makes librj.so bind to it through the shared soname, and a
+    later ``import torch`` resolves to the very same file.  Without torch installed (e.g.
+    the C++ shim) librj.so uses /opt/rocm's runtime through its DT_NEEDED entry."""
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    path = os.path.join(libdir, "libamdhip64.so")
+    if os.path.exists(path):
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def load():
     """Load librj.so (built in-tree by ``__graft_entry__.build()`` / csrc/Makefile)."""
     global _LIB
@@ -102,6 +124,7 @@ def load():
             f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
             "There is no CPU fallback."
         )
+    _preload_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int32
     L.rj_abi_version.restype = C.c_int
