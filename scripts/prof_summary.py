@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (kernel stats + PMC passes) to the rj:: kernels.
+
+usage: prof_summary.py <gpurun_out/prof dir> <out.md>
+  expects  <dir>/trace/**/_kernel_stats.csv   (--kernel-trace --stats)
+           <dir>/fetch/**/_counter_collection.csv (--pmc FETCH_SIZE)   [optional]
+           <dir>/write/**/_counter_collection.csv (--pmc WRITE_SIZE)   [optional]
+"""
+import csv
+import glob
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    m = re.search(r"rj::(k_[a-z_0-9]+)(<[^>]*(?:<[^>]*>)?[^>]*>)?", name)
+    if not m:
+        return None
+    return m.group(1) + (m.group(2) or "")
+
+
+def kernel_stats(d):
+    rows = []
+    for f in glob.glob(os.path.join(d, "trace", "**", "*_kernel_stats.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            s = short(r["Name"])
+            if s:
+                rows.append((s, int(r["Calls"]), float(r["TotalDurationNs"]), float(r["AverageNs"]), float(r["MinNs"]), float(r["MaxNs"])))
+    return sorted(rows, key=lambda x: -x[2])
+
+
+def pmc(d, sub, counter):
+    acc = defaultdict(list)
+    for f in glob.glob(os.path.join(d, sub, "**", "*_counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            s = short(r["Kernel_Name"])
+            if s and r["Counter_Name"] == counter:
+                acc[s].append(float(r["Counter_Value"]))
+    return acc
+
+
+def main():
+    d, out = sys.argv[1], sys.argv[2]
+    ks = kernel_stats(d)
+    fetch = pmc(d, "fetch", "FETCH_SIZE")
+    write = pmc(d, "write", "WRITE_SIZE")
+    lines = ["# rocprofv3 summary (rj:: kernels only)", "",
+             "| kernel | calls | total ms | avg us | min us | max us |", "|---|---|---|---|---|---|"]
+    for s, calls, tot, avg, mn, mx in ks:
+        lines.append(f"| `{s}` | {calls} | {tot/1e6:.3f} | {avg/1e3:.1f} | {mn/1e3:.1f} | {mx/1e3:.1f} |")
+    if fetch or write:
+        lines += ["", "PMC (separate passes; FETCH_SIZE / WRITE_SIZE are in KiB per dispatch; the top-N values are the",
+                  "full-size launches).  On gfx950 FETCH_SIZE reports HALF of a wide coalesced read",
+                  "(MI355X_MICROARCH.md §HBM) — `2x` column; narrower accesses are uncalibrated.", "",
+                  "| kernel | dispatches | max FETCH_SIZE MiB | x2 MiB | max WRITE_SIZE MiB |", "|---|---|---|---|---|"]
+        for s in sorted(set(fetch) | set(write)):
+            fv = max(fetch.get(s, [0])) / 1024.0
+            wv = max(write.get(s, [0])) / 1024.0
+            lines.append(f"| `{s}` | {len(fetch.get(s, write.get(s, [])))} | {fv:.1f} | {2*fv:.1f} | {wv:.1f} |")
+    open(out, "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
