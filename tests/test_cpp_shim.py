@@ -1,0 +1,53 @@
+"""The C++ drop-in boundary: radix-join_amd/host/contest_execute.cpp defines
+Contest::build_context / execute / destroy_context (reference include/plan.h:337-344)
+over the C-ABI.  tests/cpp/contest_unit_tests.cpp re-expresses the reference's 8 unit
+cases against it."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "radix-join_amd")
+OUT = os.path.join(ROOT, "tests", "cpp", "_build")
+EXE = os.path.join(OUT, "contest_unit_tests")
+
+
+def build_exe():
+    if not os.path.exists(os.path.join(PKG, "librj.so")):
+        import __graft_entry__ as g
+
+        g.build()
+    os.makedirs(OUT, exist_ok=True)
+    cmd = [
+        "g++", "-std=c++17", "-O2", "-Wall", "-Wextra",
+        "-I", os.path.join(ROOT, "include", "contest_compat"), "-I", os.path.join(ROOT, "include"),
+        os.path.join(ROOT, "tests", "cpp", "contest_unit_tests.cpp"),
+        os.path.join(PKG, "host", "contest_execute.cpp"),
+        "-L", PKG, "-lrj", f"-Wl,-rpath,{PKG}", "-Wl,-rpath,/opt/rocm/lib", "-o", EXE,
+    ]
+    subprocess.run(cmd, check=True)
+    return EXE
+
+
+def test_shim_builds_and_fails_loudly_without_gpu():
+    exe = build_exe()
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu test")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    # no GPU here: every case must fail with the library's message, never silently pass
+    assert r.returncode == 1
+    assert "no HIP device" in r.stdout
+    assert "ok " not in r.stdout
+
+
+@pytest.mark.gpu
+def test_reference_unit_cases_through_cpp_shim():
+    exe = build_exe()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for name in ["Empty join", "One line join", "Simple join", "Empty Result", "Multiple same keys", "NULL keys", "Multiple columns", "Build on right"]:
+        assert f"ok      {name}" in r.stdout

@@ -275,3 +275,27 @@ def test_resident_tables_and_virtual_ranks(ctx):
     assert (n, s, x) == pl.table_digest(want)
     tb.release()
     tp.release()
+
+
+def test_stage_a_matches_host_hash_restatement(ctx):
+    """rj_shard_partition: tuples grouped by owner rank = top bits of the library's hash
+    (pyrj.hashing restates it in numpy); keys come out hashed and un-hash to the input."""
+    from pyrj import dist, hashing
+
+    rng = np.random.default_rng(41)
+    n = 200_000
+    k = rng.integers(-(2**31), 2**31 - 1, n).astype(np.int32)
+    v = rng.random(n) > 0.1
+    t = pl.make_table([(pl.INT32, k, v), (pl.INT32, np.arange(n, dtype=np.int32))])
+    tb = ctx.upload(t)
+    ops = dist.GpuOps(ctx)
+    for n_ranks in (1, 2, 8):
+        hk, carry, counts = ops.partition(tb, n, n_ranks)
+        hk, carry = hk.cpu().numpy(), carry.cpu().numpy()
+        assert sum(counts) == int(v.sum()) == hk.shape[0]
+        keys = hashing.unfmix32(hk.view(np.uint32)).view(np.int32)
+        assert np.array_equal(keys, k[carry])  # payload = original row index
+        assert np.array_equal(np.sort(carry), np.nonzero(v)[0])
+        owner = hashing.owner_rank(keys, n_ranks)
+        assert np.array_equal(owner, np.repeat(np.arange(n_ranks), counts))
+    tb.release()
