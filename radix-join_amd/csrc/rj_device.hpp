@@ -58,11 +58,20 @@ struct Words {
 // ---- Radix partition pass --------------------------------------------------
 // One workgroup sorts a tile of PT_TILE tuples by digit in LDS and writes each
 // digit's run contiguously (software write-combining), see rj_kernels.hip.
-constexpr int PT_THREADS = 512;                   // 8 waves
-constexpr int PT_ITEMS   = 16;                    // tuples per thread per tile
+// Geometry is overridable at build time (-DRJ_PT_THREADS=...) for tuning runs.
+#ifndef RJ_PT_THREADS
+#define RJ_PT_THREADS 512
+#endif
+#ifndef RJ_PT_ITEMS
+#define RJ_PT_ITEMS 16
+#endif
+constexpr int PT_THREADS = RJ_PT_THREADS;         // waves = PT_THREADS / 64
+constexpr int PT_ITEMS   = RJ_PT_ITEMS;           // tuples per thread per tile
 constexpr int PT_TILE    = PT_THREADS * PT_ITEMS; // 8192 tuples = 32 KiB per word array
 constexpr int PT_MAXF    = 512;                   // max fan-out per pass (9 bits)
 constexpr int PT_MAXBITS = 9;
+static_assert(PT_THREADS >= PT_MAXF, "thread d scans digit d");
+static_assert(PT_TILE <= 65536, "ranks are packed into 16 bits");
 
 struct PassParams {
     const uint32_t* seg_off;    // [nseg+1] input segments (previous pass' partitions);
@@ -79,13 +88,29 @@ struct PassParams {
 };
 
 // ---- Build/probe -------------------------------------------------------------
-constexpr int      JN_THREADS = 512;
-constexpr int      JN_SPT     = 8;                     // probe tuples per thread per sub-chunk
-constexpr int      JN_SUB     = JN_THREADS * JN_SPT;   // 4096
-constexpr int      JN_CAP     = 8192;                  // LDS table slots
+#ifndef RJ_JN_THREADS
+#define RJ_JN_THREADS 512
+#endif
+#ifndef RJ_JN_SPT
+#define RJ_JN_SPT 8
+#endif
+#ifndef RJ_JN_CAP
+#define RJ_JN_CAP 8192
+#endif
+constexpr int      JN_THREADS = RJ_JN_THREADS;
+constexpr int      JN_SPT     = RJ_JN_SPT;             // probe tuples per thread per sub-chunk
+constexpr int      JN_SUB     = JN_THREADS * JN_SPT;   // probe tuples per output reservation
+constexpr int      JN_CAP     = RJ_JN_CAP;             // LDS table slots (power of two)
 constexpr int      JN_RMAX    = JN_CAP / 2;            // build tuples per table (load <= 50 %)
+constexpr int      JN_RPT     = (JN_RMAX + JN_THREADS - 1) / JN_THREADS;  // build tuples per thread
+// workgroups per CU the LDS table allows (2 words per slot in the common case), and the
+// matching __launch_bounds__ "waves per SIMD" = blocks/CU * threads / 256, capped at 8
+constexpr int      JN_BLOCKS_PER_CU = (160 * 1024) / (JN_CAP * 8 + 1024);
+constexpr int      JN_MIN_WAVES =
+    (JN_BLOCKS_PER_CU * JN_THREADS / 256) > 8 ? 8
+    : ((JN_BLOCKS_PER_CU * JN_THREADS / 256) < 1 ? 1 : (JN_BLOCKS_PER_CU * JN_THREADS / 256));
 constexpr uint32_t JN_HEAVY   = 32768;                 // probe tuples per task before splitting
-constexpr uint32_t JN_TARGET_BUILD = 3072;             // mean build tuples per final partition
+constexpr uint32_t JN_TARGET_BUILD = JN_RMAX * 3 / 4;  // mean build tuples per final partition
 
 enum StreamMode : int32_t {
     ST_NONE    = 0,
@@ -107,6 +132,8 @@ struct JoinParams {
     const uint32_t* offS;   // [NP+1]
     uint32_t        NP;
     uint32_t        radix_bits;  // low bits of word 0 shared by a partition's tuples
+    uint32_t        n_pass;      // radix passes and their bit widths: partition index
+    uint32_t        pass_bits[4]; //   q = ((d1 * F2) + d2) * F3 + d3, hash low bits = d1 | d2 << b1 | ...
     OutStream       key, bc, pc; // emitted streams: key, build carry, probe carry
     unsigned long long* out_cursor;
     uint64_t        out_cap;     // rows that fit the stream buffers

@@ -11,6 +11,7 @@
 //     row index into the child, gathered per output column.
 //   * At the root the streams are written straight into Page images.
 #include <algorithm>
+#include <cstdlib>
 #include <set>
 
 #include "rj_internal.hpp"
@@ -42,6 +43,7 @@ struct Parted {
     Words    w{};
     BufP     off;  // u32[NP+1]
     uint32_t NP = 0;
+    std::vector<uint32_t> pbits;  // radix bits of each pass
 };
 
 struct JoinSpec {
@@ -52,6 +54,11 @@ struct JoinSpec {
     bool                  prehashed = false;
     int                   forced_bits = 0;
 };
+
+int tune(const char* name, int def) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : def;
+}
 
 uint32_t ceil_log2(uint64_t v) {
     uint32_t b = 0;
@@ -279,6 +286,14 @@ class Exec {
         if (passes == 0) passes = 1;
         std::vector<uint32_t> pbits(passes, bits / passes);
         for (uint32_t i = 0; i < bits % passes; ++i) pbits[i]++;
+        // tuning knobs (experiments): RJ_TUNE_P1_BITS moves bits between pass 1 and pass 2
+        if (passes == 2 && tune("RJ_TUNE_P1_BITS", 0) > 0) {
+            uint32_t b1 = (uint32_t)tune("RJ_TUNE_P1_BITS", 0);
+            if (b1 < bits && b1 <= PT_MAXBITS && bits - b1 <= PT_MAXBITS) {
+                pbits[0] = b1;
+                pbits[1] = bits - b1;
+            }
+        }
 
         BufP  A[MAX_WORDS], B[MAX_WORDS];
         Words wa{}, wb{};
@@ -310,6 +325,7 @@ class Exec {
             BufP     grp_start;
             if (p == 0) {
                 pp.tiles_per_group = tiles_per_group(n, 4096);
+                if (tune("RJ_TUNE_TPG1", 0) > 0) pp.tiles_per_group = (uint32_t)tune("RJ_TUNE_TPG1", 0);
                 uint64_t gt = (uint64_t)pp.tiles_per_group * PT_TILE;
                 n_groups = (uint32_t)((n + gt - 1) / gt);
             } else {
@@ -332,11 +348,11 @@ class Exec {
             pp.cursor = cursor->as<uint32_t>();
             if (p == 0) {
                 launch_pass_hist_src(L, src, KW, pp, n_groups);
-                launch_scan_bins(L, pp.hist, (uint32_t)bins, off->as<uint32_t>(), pp.cursor);
+                launch_scan_segments(L, pp.hist, nullptr, 1, F, off->as<uint32_t>(), pp.cursor);
                 launch_pass_scatter_src(L, src, KW, CW, pp, n_groups, nxt);
             } else {
                 launch_pass_hist_dense(L, cur, pp, n_groups);
-                launch_scan_bins(L, pp.hist, (uint32_t)bins, off->as<uint32_t>(), pp.cursor);
+                launch_scan_segments(L, pp.hist, pp.seg_off, nseg, F, off->as<uint32_t>(), pp.cursor);
                 launch_pass_scatter_dense(L, cur, P.NW, pp, n_groups, nxt);
             }
             seg_off = off;
@@ -350,6 +366,7 @@ class Exec {
         for (int a = 0; a < P.NW; ++a) P.wbuf[a] = cur_is_a ? A[a] : B[a];
         P.off = seg_off;
         P.NP = nseg;
+        P.pbits = pbits;
         return P;
     }
 
@@ -464,7 +481,11 @@ class Exec {
             src.key = s.rel->cols[s.key_col].ref();
             src.n_rows = (uint32_t)s.rel->n;
             src.carry_mode = s.carry_mode;
-            if (s.carry_mode == CARRY_COLUMN) src.carry = s.rel->cols[s.carry_col].ref();
+            if (s.carry_mode == CARRY_COLUMN) {
+                src.carry = s.rel->cols[s.carry_col].ref();
+                // a base table's row-id column (VARCHAR stand-in) IS the row index
+                if (src.carry.kind == COL_IOTA) src.carry_mode = CARRY_ROWIDX;
+            }
             src.key_f64 = f64 ? 1 : 0;
             src.prehashed = js.prehashed ? 1 : 0;
             return src;
@@ -475,7 +496,7 @@ class Exec {
         // heavy probe partitions -> task list
         uint32_t max_tasks = (uint32_t)(2 * (ps.rel->n / JN_HEAVY) + 2);
         BufP     tasks = ctx->buf((uint64_t)max_tasks * 12);
-        BufP     counters = ctx->buf(16);  // [0..7] out cursor (u64), [8..11] n_heavy
+        BufP     counters = ctx->buf(2048);  // [0..7] out cursor (u64), [8..11] n_heavy
         launch_heavy_tasks_zeroed(PB, PP, tasks, counters, max_tasks);
 
         // stream destinations
@@ -514,6 +535,7 @@ class Exec {
                 s->stream = s->stream_mode != ST_NONE ? ctx->buf(stream_bytes(s->stream_mode, cap))
                                                       : BufP();
             RJ_HIP(hipMemsetAsync(counters->p, 0, 8, ctx->stream));
+            RJ_HIP(hipMemsetAsync(counters->as<uint8_t>() + 16, 0, 2048 - 16, ctx->stream));
             JoinParams jp{};
             jp.R = PB.w;
             jp.S = PP.w;
@@ -521,6 +543,8 @@ class Exec {
             jp.offS = PP.off->as<uint32_t>();
             jp.NP = PB.NP;
             jp.radix_bits = bits;
+            jp.n_pass = (uint32_t)PB.pbits.size();
+            for (size_t i = 0; i < PB.pbits.size() && i < 4; ++i) jp.pass_bits[i] = PB.pbits[i];
             jp.key = OutStream{key_stream ? key_stream->as<uint8_t>() : nullptr, key_mode, 0};
             jp.bc = OutStream{bs.stream ? bs.stream->as<uint8_t>() : nullptr, bs.stream_mode, 0};
             jp.pc = OutStream{ps.stream ? ps.stream->as<uint8_t>() : nullptr, ps.stream_mode, 0};

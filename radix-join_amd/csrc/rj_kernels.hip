@@ -62,9 +62,18 @@ __device__ __forceinline__ uint32_t lane_prefix(uint64_t mask) {
                                      __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for
+// vmcnt(0), i.e. for every outstanding global load AND store of the wave; the kernels
+// below never hand global data from wave to wave inside a launch, so their barriers only
+// need the LDS counter drained — global stores then retire asynchronously behind the
+// next phase instead of stalling every barrier.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // Exclusive scan of one value per thread across the workgroup (blockDim.x a
 // multiple of 64, at most 1024).  s_wsum needs blockDim.x/64 words.  Contains
-// one __syncthreads(); the caller must sync again before reusing s_wsum.
+// one barrier; the caller must sync again before reusing s_wsum.
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_wsum, uint32_t& total) {
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     uint32_t       incl = v;
@@ -74,7 +83,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_wsum
         if (lane >= (uint32_t)off) incl += t;
     }
     if (lane == 63) s_wsum[wid] = incl;
-    __syncthreads();
+    lds_barrier();
     uint32_t wbase = 0, tot = 0;
     for (uint32_t k = 0; k < nw; ++k) {
         uint32_t s = s_wsum[k];
@@ -217,21 +226,74 @@ __global__ __launch_bounds__(1024) void k_scan_bins(const uint32_t* in, uint32_t
     if (threadIdx.x == 0) off[n] = total;
 }
 
+// Exclusive scan of the bins of ONE input segment per workgroup.  A segment's tuples are
+// exactly the sum of its bins (NULL keys were dropped in the first pass), so the global
+// offset of bin (seg, d) is seg_off[seg] + prefix inside the segment: every segment scans
+// independently instead of one workgroup walking all nseg*F bins.
+__global__ __launch_bounds__(PT_MAXF) void k_scan_segments(const uint32_t* hist,
+                                                           const uint32_t* seg_off, uint32_t nseg,
+                                                           uint32_t F, uint32_t* off,
+                                                           uint32_t* cursor) {
+    __shared__ uint32_t s_wsum[PT_MAXF / 64];
+    const uint32_t      seg = blockIdx.x, d = threadIdx.x;
+    const uint32_t      v = d < F ? hist[(size_t)seg * F + d] : 0u;
+    uint32_t            total;
+    const uint32_t      ex = block_excl_scan(v, s_wsum, total);
+    const uint32_t      base = seg_off ? seg_off[seg] : 0u;
+    if (d < F) {
+        off[(size_t)seg * F + d] = base + ex;
+        cursor[(size_t)seg * F + d] = base + ex;
+    }
+    if (seg + 1 == nseg && d == 0) off[(size_t)nseg * F] = base + total;
+}
+
 // ========================================================== tuple loaders (K2/K4)
 // Loader concept:  key(i, hk) -> valid      load<NW>(i, w) -> valid
+// A loader fills one tile: item j of thread t is element base + j*PT_THREADS + t.  Every
+// load is UNCONDITIONAL (the index is clamped to the last valid element) and all uniform
+// decisions (column kind, validity array present, carry mode) are taken once per tile, so
+// the compiler can issue the whole tile's loads back to back behind a single wait.  The
+// returned bit mask says which items hold a tuple.
 struct DenseLoader {
     Words in;
-    __device__ __forceinline__ bool key(uint32_t i, uint32_t& hk) const {
-        hk = in.w[0][i];
-        return true;
+    __device__ __forceinline__ uint32_t key_tile(uint32_t base, uint32_t end,
+                                                 uint32_t (&hk)[PT_ITEMS]) const {
+        uint32_t ok = 0;
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS; ++j) {
+            uint32_t i = base + j * PT_THREADS + threadIdx.x;
+            hk[j] = in.w[0][min(i, end - 1u)];
+            ok |= (uint32_t)(i < end) << j;
+        }
+        return ok;
     }
     template <int NW>
-    __device__ __forceinline__ bool load(uint32_t i, uint32_t (&w)[NW]) const {
+    __device__ __forceinline__ uint32_t load_tile(uint32_t base, uint32_t end,
+                                                  uint32_t (&w)[PT_ITEMS][NW]) const {
+        uint32_t ok = 0;
 #pragma unroll
-        for (int a = 0; a < NW; ++a) w[a] = in.w[a][i];
-        return true;
+        for (int j = 0; j < PT_ITEMS; ++j) {
+            uint32_t i = base + j * PT_THREADS + threadIdx.x;
+            uint32_t ic = min(i, end - 1u);
+#pragma unroll
+            for (int a = 0; a < NW; ++a) w[j][a] = in.w[a][ic];
+            ok |= (uint32_t)(i < end) << j;
+        }
+        return ok;
     }
 };
+
+// byte offset of row `row` in a 4-byte / 8-byte column (regular page images or dense)
+__device__ __forceinline__ uint64_t col_off32(bool paged, uint32_t row) {
+    uint32_t p = row / ROWS32, i = row - p * ROWS32;
+    uint64_t po = (uint64_t)p * PAGE_BYTES + HDR32 + i * 4u;
+    return paged ? po : (uint64_t)row * 4u;
+}
+__device__ __forceinline__ uint64_t col_off64(bool paged, uint32_t row) {
+    uint32_t p = row / ROWS64, i = row - p * ROWS64;
+    uint64_t po = (uint64_t)p * PAGE_BYTES + HDR64 + i * 8u;
+    return paged ? po : (uint64_t)row * 8u;
+}
 
 // Forms tuples straight from columns: page decode (regular pages), NULL-key
 // drop (reference src/execute.cpp:62-83: only rows whose variant holds KeyType
@@ -239,51 +301,105 @@ struct DenseLoader {
 template <int KW, int CW>
 struct SrcLoader {
     TupleSrc s;
-    __device__ __forceinline__ bool key2(uint32_t row, uint32_t& lo, uint32_t& hi) const {
-        if (s.key.valid && !s.key.valid[row]) return false;
-        if (KW == 1) {
-            uint32_t k = col_load32(s.key, row);
-            lo = s.prehashed ? k : fmix32(k);
-            hi = 0;
-            return true;
-        }
-        uint64_t k = col_load64(s.key, row);
-        if (s.key_f64) {
-            // The reference hashes the BIT PATTERN of a double (src/execute.cpp:28-31) and
-            // compares with == (:215,231): NaN equals nothing, and -0.0 / +0.0 hash to
-            // different slots so they only meet by accident of probing.  Bit-pattern
-            // equality with NaN excluded reproduces that (SURVEY.md §8a note on FP64).
-            if ((k & 0x7ff0000000000000ull) == 0x7ff0000000000000ull && (k & 0x000fffffffffffffull))
-                return false;
-        }
-        uint64_t h = fmix64(k);
-        lo = (uint32_t)h;
-        hi = (uint32_t)(h >> 32);
-        return true;
-    }
-    __device__ __forceinline__ bool key(uint32_t row, uint32_t& hk) const {
-        uint32_t hi;
-        return key2(row, hk, hi);
-    }
-    template <int NW>
-    __device__ __forceinline__ bool load(uint32_t row, uint32_t (&w)[NW]) const {
-        static_assert(NW == KW + CW, "word count");
-        uint32_t lo, hi;
-        if (!key2(row, lo, hi)) return false;
-        w[0] = lo;
-        if (KW == 2) w[1] = hi;
-        if constexpr (CW >= 1) {
-            if (s.carry_mode == CARRY_ROWIDX) {
-                w[KW] = row;  // CW == 1 by construction
-            } else if constexpr (CW == 1) {
-                w[KW] = col_load32(s.carry, row);
+
+    // raw key words of the tile + validity mask
+    __device__ __forceinline__ uint32_t raw_keys(uint32_t base, uint32_t end,
+                                                 uint32_t (&lo)[PT_ITEMS],
+                                                 uint32_t (&hi)[PT_ITEMS]) const {
+        const bool     paged = s.key.kind == COL_PAGED;
+        const uint8_t* kp = s.key.ptr;
+        uint32_t       ok = 0;
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS; ++j) {
+            uint32_t i = base + j * PT_THREADS + threadIdx.x;
+            uint32_t ic = min(i, end - 1u);
+            if constexpr (KW == 1) {
+                lo[j] = *reinterpret_cast<const uint32_t*>(kp + col_off32(paged, ic));
+                hi[j] = 0;
             } else {
-                uint64_t v = col_load64(s.carry, row);
-                w[KW] = (uint32_t)v;
-                w[KW + 1] = (uint32_t)(v >> 32);
+                uint64_t k = *reinterpret_cast<const uint64_t*>(kp + col_off64(paged, ic));
+                lo[j] = (uint32_t)k;
+                hi[j] = (uint32_t)(k >> 32);
+            }
+            ok |= (uint32_t)(i < end) << j;
+        }
+        return ok;
+    }
+    __device__ __forceinline__ uint32_t drop_invalid(uint32_t base, uint32_t end, uint32_t ok) const {
+        const uint8_t* vp = s.key.valid;
+        if (vp) {  // uniform: the column was decoded by K1 and carries validity bytes
+#pragma unroll
+            for (int j = 0; j < PT_ITEMS; ++j) {
+                uint32_t i = base + j * PT_THREADS + threadIdx.x;
+                if (!vp[min(i, end - 1u)]) ok &= ~(1u << j);
             }
         }
-        return true;
+        return ok;
+    }
+    // hash in place; FP64: NaN never matches (see key semantics below)
+    __device__ __forceinline__ uint32_t hash_keys(uint32_t ok, uint32_t (&lo)[PT_ITEMS],
+                                                  uint32_t (&hi)[PT_ITEMS]) const {
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS; ++j) {
+            if constexpr (KW == 1) {
+                lo[j] = s.prehashed ? lo[j] : fmix32(lo[j]);
+            } else {
+                uint64_t k = (uint64_t)lo[j] | ((uint64_t)hi[j] << 32);
+                // The reference hashes the BIT PATTERN of a double (src/execute.cpp:28-31) and
+                // compares with == (:215,231): NaN equals nothing, and -0.0 / +0.0 hash to
+                // different slots so they only meet by accident of probing.  Bit-pattern
+                // equality with NaN excluded reproduces that (SURVEY.md §8a note on FP64).
+                if (s.key_f64 && (k & 0x7ff0000000000000ull) == 0x7ff0000000000000ull &&
+                    (k & 0x000fffffffffffffull))
+                    ok &= ~(1u << j);
+                uint64_t h = fmix64(k);
+                lo[j] = (uint32_t)h;
+                hi[j] = (uint32_t)(h >> 32);
+            }
+        }
+        return ok;
+    }
+    __device__ __forceinline__ uint32_t key_tile(uint32_t base, uint32_t end,
+                                                 uint32_t (&hk)[PT_ITEMS]) const {
+        uint32_t hi[PT_ITEMS];
+        uint32_t ok = raw_keys(base, end, hk, hi);
+        ok = drop_invalid(base, end, ok);
+        return hash_keys(ok, hk, hi);
+    }
+    template <int NW>
+    __device__ __forceinline__ uint32_t load_tile(uint32_t base, uint32_t end,
+                                                  uint32_t (&w)[PT_ITEMS][NW]) const {
+        static_assert(NW == KW + CW, "word count");
+        uint32_t lo[PT_ITEMS], hi[PT_ITEMS];
+        uint32_t ok = raw_keys(base, end, lo, hi);
+        if constexpr (CW >= 1) {
+            if (s.carry_mode == CARRY_ROWIDX) {  // CW == 1 by construction
+#pragma unroll
+                for (int j = 0; j < PT_ITEMS; ++j) w[j][KW] = base + j * PT_THREADS + threadIdx.x;
+            } else {
+                const bool     paged = s.carry.kind == COL_PAGED;
+                const uint8_t* cp = s.carry.ptr;
+#pragma unroll
+                for (int j = 0; j < PT_ITEMS; ++j) {
+                    uint32_t ic = min(base + j * PT_THREADS + threadIdx.x, end - 1u);
+                    if constexpr (CW == 1) {
+                        w[j][KW] = *reinterpret_cast<const uint32_t*>(cp + col_off32(paged, ic));
+                    } else {
+                        uint64_t v = *reinterpret_cast<const uint64_t*>(cp + col_off64(paged, ic));
+                        w[j][KW] = (uint32_t)v;
+                        w[j][KW + 1] = (uint32_t)(v >> 32);
+                    }
+                }
+            }
+        }
+        ok = drop_invalid(base, end, ok);
+        ok = hash_keys(ok, lo, hi);
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS; ++j) {
+            w[j][0] = lo[j];
+            if constexpr (KW == 2) w[j][1] = hi[j];
+        }
+        return ok;
     }
 };
 
@@ -328,16 +444,15 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_hist(Loader ld, PassParams 
     if (!group_range(pp, blockIdx.x, seg, begin, end)) return;
     const uint32_t F = 1u << pp.fanout_log2, mask = F - 1u;
     for (uint32_t d = threadIdx.x; d < F; d += PT_THREADS) s_h[d] = 0;
-    __syncthreads();
+    lds_barrier();
     for (uint32_t base = begin; base < end; base += PT_TILE) {
-#pragma unroll 4
-        for (int j = 0; j < PT_ITEMS; ++j) {
-            uint32_t i = base + j * PT_THREADS + threadIdx.x;
-            uint32_t hk;
-            if (i < end && ld.key(i, hk)) atomicAdd(&s_h[(hk >> pp.shift) & mask], 1u);
-        }
+        uint32_t hk[PT_ITEMS];
+        uint32_t ok = ld.key_tile(base, end, hk);
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS; ++j)
+            if ((ok >> j) & 1u) atomicAdd(&s_h[(hk[j] >> pp.shift) & mask], 1u);
     }
-    __syncthreads();
+    lds_barrier();
     for (uint32_t d = threadIdx.x; d < F; d += PT_THREADS) {
         uint32_t c = s_h[d];
         pp.group_hist[(size_t)blockIdx.x * F + d] = c;
@@ -360,41 +475,49 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassPara
     __shared__ uint16_t s_dig[PT_TILE];
     __shared__ uint32_t s_cnt[PT_MAXF];
     __shared__ uint32_t s_base[PT_MAXF];
-    __shared__ uint32_t s_run[PT_MAXF];
+    __shared__ uint32_t s_delta[PT_MAXF];
     __shared__ uint32_t s_wsum[PT_THREADS / 64];
     uint32_t            seg, begin, end;
     if (!group_range(pp, blockIdx.x, seg, begin, end)) return;
     const uint32_t F = 1u << pp.fanout_log2, mask = F - 1u;
 
-    for (uint32_t d = threadIdx.x; d < F; d += PT_THREADS) {
-        uint32_t c = pp.group_hist[(size_t)blockIdx.x * F + d];
-        s_run[d] = c ? atomicAdd(&pp.cursor[(size_t)seg * F + d], c) : 0u;
+    // Thread d owns digit d's write cursor in a REGISTER: the reservation's round trip is
+    // not waited for until the first tile has been loaded and ranked.
+    uint32_t run = 0;
+    if (threadIdx.x < F) {
+        uint32_t c = pp.group_hist[(size_t)blockIdx.x * F + threadIdx.x];
+        if (c) run = atomicAdd(&pp.cursor[(size_t)seg * F + threadIdx.x], c);
     }
 
     for (uint32_t base = begin; base < end; base += PT_TILE) {
         for (uint32_t d = threadIdx.x; d < F; d += PT_THREADS) s_cnt[d] = 0;
-        __syncthreads();
+        lds_barrier();
 
         uint32_t w[PT_ITEMS][NW];
         uint32_t dr[PT_ITEMS];  // digit << 16 | rank, 0xffffffff = no tuple
+        // every load of the tile is issued before the first rank is taken
+        const uint32_t ok = ld.template load_tile<NW>(base, end, w);
 #pragma unroll
         for (int j = 0; j < PT_ITEMS; ++j) {
-            uint32_t i = base + j * PT_THREADS + threadIdx.x;
             dr[j] = 0xffffffffu;
-            if (i < end && ld.template load<NW>(i, w[j])) {
+            if ((ok >> j) & 1u) {
                 uint32_t d = (w[j][0] >> pp.shift) & mask;
                 uint32_t r = atomicAdd(&s_cnt[d], 1u);
                 dr[j] = (d << 16) | r;
             }
         }
-        __syncthreads();
+        lds_barrier();
 
-        // PT_MAXF == PT_THREADS: thread d scans digit d
+        // PT_THREADS >= PT_MAXF: thread d scans digit d
         uint32_t c = threadIdx.x < F ? s_cnt[threadIdx.x] : 0u;
         uint32_t total;
         uint32_t ex = block_excl_scan(c, s_wsum, total);
-        if (threadIdx.x < F) s_base[threadIdx.x] = ex;
-        __syncthreads();
+        if (threadIdx.x < F) {
+            s_base[threadIdx.x] = ex;
+            s_delta[threadIdx.x] = run - ex;  // global index = delta + LDS position
+            run += c;
+        }
+        lds_barrier();
 
 #pragma unroll
         for (int a = 0; a < NW; ++a) {
@@ -407,17 +530,12 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassPara
                     if (a == 0) s_dig[pos] = (uint16_t)d;
                 }
             }
-            __syncthreads();
+            lds_barrier();
             uint32_t* dst = out.w[a];
-            for (uint32_t i = threadIdx.x; i < total; i += PT_THREADS) {
-                uint32_t d = s_dig[i];
-                dst[s_run[d] + (i - s_base[d])] = s_stage[i];
-            }
-            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < total; i += PT_THREADS)
+                dst[s_delta[s_dig[i]] + i] = s_stage[i];
+            lds_barrier();
         }
-        for (uint32_t d = threadIdx.x; d < F; d += PT_THREADS) s_run[d] += s_cnt[d];
-        // the next iteration's s_cnt reset is done by the same thread d, and is
-        // followed by a barrier before any atomic touches it
     }
 }
 
@@ -458,8 +576,9 @@ __global__ void k_heavy_tasks(const uint32_t* offR, const uint32_t* offS, uint32
 // A build partition larger than JN_RMAX is processed in table-sized chunks
 // (block nested loop), which keeps any duplicate-heavy input correct.
 template <int KW, int CWR, int CWS>
-__global__ __launch_bounds__(JN_THREADS) void k_join(JoinParams jp) {
+__global__ __launch_bounds__(JN_THREADS, JN_MIN_WAVES) void k_join(JoinParams jp) {
     constexpr int      RW = KW + CWR;  // LDS table arrays (one per word)
+    constexpr int      SW = KW + CWS;
     __shared__ uint32_t t_w[RW][JN_CAP];
     __shared__ uint32_t s_wtot[JN_THREADS / 64];
     __shared__ unsigned long long s_obase;
@@ -481,53 +600,83 @@ __global__ __launch_bounds__(JN_THREADS) void k_join(JoinParams jp) {
     if (rbeg == rend || sbeg == send) return;
 
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
-    const uint32_t rmask = (jp.radix_bits >= 32) ? 0xffffffffu : ((1u << jp.radix_bits) - 1u);
-    const uint32_t EMPTY = (jp.R.w[0][rbeg] & rmask) ^ 1u;
+    // The low radix bits every hashed key of partition q shares, rebuilt from q
+    // (q = ((d1*F2)+d2)*F3+d3, hash low bits = d1 | d2<<b1 | d3<<(b1+b2)); EMPTY differs
+    // from them in bit 0, so no stored key can equal it.
+    uint32_t qbits = 0;
+    {
+        uint32_t rem = q, sh = jp.radix_bits;
+        for (int p = (int)jp.n_pass - 1; p >= 0; --p) {
+            uint32_t b = jp.pass_bits[p];
+            sh -= b;
+            qbits |= (rem & ((1u << b) - 1u)) << sh;
+            rem >>= b;
+        }
+    }
+    const uint32_t EMPTY = qbits ^ 1u;
     constexpr uint32_t SMASK = JN_CAP - 1;
 
     for (uint32_t rc = rbeg; rc < rend; rc += JN_RMAX) {
         const uint32_t rn = min((uint32_t)JN_RMAX, rend - rc);
-        for (uint32_t i = threadIdx.x; i < JN_CAP; i += JN_THREADS) t_w[0][i] = EMPTY;
-        __syncthreads();
-        // ---- build
-        for (uint32_t i = threadIdx.x; i < rn; i += JN_THREADS) {
-            uint32_t rw[RW];
+        // ---- issue the build loads and the first probe sub-chunk together: one HBM
+        //      latency instead of two, both land while the table is being cleared
+        uint32_t rw[JN_RPT][RW];
 #pragma unroll
-            for (int a = 0; a < RW; ++a) rw[a] = jp.R.w[a][rc + i];
-            uint32_t slot = (rw[0] >> jp.radix_bits) & SMASK;
-            while (true) {
-                uint32_t old = atomicCAS(&t_w[0][slot], EMPTY, rw[0]);
-                if (old == EMPTY) {
+        for (int j = 0; j < JN_RPT; ++j) {
+            uint32_t i = j * JN_THREADS + threadIdx.x;
+            if (i < rn) {
 #pragma unroll
-                    for (int a = 1; a < RW; ++a) t_w[a][slot] = rw[a];
-                    break;
-                }
-                slot = (slot + 1) & SMASK;
+                for (int a = 0; a < RW; ++a) rw[j][a] = jp.R.w[a][rc + i];
             }
         }
-        __syncthreads();
+        uint32_t sw[JN_SPT][SW];
+        {
+            const uint32_t sn0 = min((uint32_t)JN_SUB, send - sbeg);
+#pragma unroll
+            for (int j = 0; j < JN_SPT; ++j) {
+                uint32_t i = j * JN_THREADS + threadIdx.x;
+#pragma unroll
+                for (int a = 0; a < SW; ++a) sw[j][a] = i < sn0 ? jp.S.w[a][sbeg + i] : 0u;
+            }
+        }
+        for (uint32_t i = threadIdx.x; i < JN_CAP; i += JN_THREADS) t_w[0][i] = EMPTY;
+        lds_barrier();
+        // ---- build
+#pragma unroll
+        for (int j = 0; j < JN_RPT; ++j) {
+            uint32_t i = j * JN_THREADS + threadIdx.x;
+            if (i < rn) {
+                uint32_t slot = (rw[j][0] >> jp.radix_bits) & SMASK;
+                while (true) {
+                    uint32_t old = atomicCAS(&t_w[0][slot], EMPTY, rw[j][0]);
+                    if (old == EMPTY) {
+#pragma unroll
+                        for (int a = 1; a < RW; ++a) t_w[a][slot] = rw[j][a];
+                        break;
+                    }
+                    slot = (slot + 1) & SMASK;
+                }
+            }
+        }
+        lds_barrier();
         // ---- probe, JN_SUB tuples at a time
         for (uint32_t sc = sbeg; sc < send; sc += JN_SUB) {
             const uint32_t sn = min((uint32_t)JN_SUB, send - sc);
-            uint32_t       sw[JN_SPT][KW + CWS];
-            uint32_t       m[JN_SPT], f[JN_SPT];
+            if (sc != sbeg) {
+#pragma unroll
+                for (int j = 0; j < JN_SPT; ++j) {
+                    uint32_t i = j * JN_THREADS + threadIdx.x;
+#pragma unroll
+                    for (int a = 0; a < SW; ++a) sw[j][a] = i < sn ? jp.S.w[a][sc + i] : 0u;
+                }
+            }
+            uint32_t m[JN_SPT], f[JN_SPT];
+            // count matches, remember the first matching slot
 #pragma unroll
             for (int j = 0; j < JN_SPT; ++j) {
                 uint32_t i = j * JN_THREADS + threadIdx.x;
                 m[j] = 0;
                 f[j] = 0;
-                if (i < sn) {
-#pragma unroll
-                    for (int a = 0; a < KW + CWS; ++a) sw[j][a] = jp.S.w[a][sc + i];
-                } else {
-#pragma unroll
-                    for (int a = 0; a < KW + CWS; ++a) sw[j][a] = 0;
-                }
-            }
-            // count matches, remember the first matching slot
-#pragma unroll
-            for (int j = 0; j < JN_SPT; ++j) {
-                uint32_t i = j * JN_THREADS + threadIdx.x;
                 if (i < sn) {
                     uint32_t slot = (sw[j][0] >> jp.radix_bits) & SMASK;
                     while (true) {
@@ -568,15 +717,22 @@ __global__ __launch_bounds__(JN_THREADS) void k_join(JoinParams jp) {
                 wave_total += tot;
             }
             if (lane == 0) s_wtot[wid] = wave_total;
-            __syncthreads();
+            lds_barrier();
             if (threadIdx.x == 0) {
                 uint32_t tot = 0;
                 for (int k = 0; k < JN_THREADS / 64; ++k) tot += s_wtot[k];
+#if defined(RJ_ABL_NO_ATOMIC)
+                s_obase = sc;  // timing experiment: rows = probe positions (valid only for PK-FK)
+#elif defined(RJ_ABL_CURSOR_SHARD)
+                s_obase = tot ? atomicAdd(jp.out_cursor + 16 * (blockIdx.x & 7), (unsigned long long)tot) : 0ull;
+#else
                 s_obase = tot ? atomicAdd(jp.out_cursor, (unsigned long long)tot) : 0ull;
+#endif
             }
-            __syncthreads();
-            uint64_t obase = s_obase;
-            uint32_t block_total = 0;
+            lds_barrier();
+            const uint64_t gbase = s_obase;
+            uint64_t       obase = gbase;
+            uint32_t       block_total = 0;
             for (uint32_t k = 0; k < JN_THREADS / 64; ++k) {
                 uint32_t t = s_wtot[k];
                 if (k < wid) obase += t;
@@ -584,7 +740,11 @@ __global__ __launch_bounds__(JN_THREADS) void k_join(JoinParams jp) {
             }
             // rows beyond the stream capacity are counted but not written; the host
             // re-runs the join with exact-size buffers (out_cursor = rows needed)
-            const bool fits = s_obase + block_total <= jp.out_cap;
+#if defined(RJ_ABL_NO_STORE)
+            const bool fits = false;
+#else
+            const bool fits = gbase + block_total <= jp.out_cap;
+#endif
             if (fits) {
 #pragma unroll
                 for (int j = 0; j < JN_SPT; ++j) {
@@ -618,9 +778,9 @@ __global__ __launch_bounds__(JN_THREADS) void k_join(JoinParams jp) {
                     }
                 }
             }
-            __syncthreads();  // s_wtot / s_obase are reused by the next sub-chunk
+            lds_barrier();  // s_wtot / s_obase are reused by the next sub-chunk
         }
-        __syncthreads();  // table is cleared for the next build chunk
+        lds_barrier();  // table is cleared for the next build chunk
     }
 }
 
@@ -751,6 +911,12 @@ void launch_decode_pages(const Launch& L, const uint8_t* pages, uint32_t n_pages
 void launch_scan_bins(const Launch& L, const uint32_t* in, uint32_t n, uint32_t* off,
                       uint32_t* cursor) {
     RJ_KLAUNCH(L, "scan_bins", (k_scan_bins<0>), 1, 1024, in, n, 1u, off, cursor);
+}
+
+void launch_scan_segments(const Launch& L, const uint32_t* hist, const uint32_t* seg_off,
+                          uint32_t nseg, uint32_t F, uint32_t* off, uint32_t* cursor) {
+    RJ_KLAUNCH(L, "scan_segments", k_scan_segments, nseg, PT_MAXF, hist, seg_off, nseg, F, off,
+               cursor);
 }
 
 void launch_group_table(const Launch& L, const uint32_t* seg_off, uint32_t nseg,

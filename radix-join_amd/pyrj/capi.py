@@ -119,13 +119,14 @@ def load():
     global _LIB
     if _LIB is not None:
         return _LIB
-    if not os.path.exists(LIB_PATH):
+    lib_path = os.environ.get("RJ_LIB_PATH", LIB_PATH)  # tuning variants: csrc/Makefile
+    if not os.path.exists(lib_path):
         raise RuntimeError(
-            f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+            f"{lib_path} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
             "There is no CPU fallback."
         )
     _preload_torch_hip_runtime()
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(lib_path)
     vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int32
     L.rj_abi_version.restype = C.c_int
     L.rj_context_create.argtypes = [C.POINTER(vp), C.POINTER(rj_config)]
