@@ -72,6 +72,7 @@ constexpr int PT_MAXF    = 512;                   // max fan-out per pass (9 bit
 constexpr int PT_MAXBITS = 9;
 static_assert(PT_THREADS >= PT_MAXF, "thread d scans digit d");
 static_assert(PT_TILE <= 65536, "ranks are packed into 16 bits");
+static_assert(PT_ITEMS % 4 == 0, "full tiles are loaded as 16-byte vectors");
 
 struct PassParams {
     const uint32_t* seg_off;    // [nseg+1] input segments (previous pass' partitions);
@@ -103,12 +104,18 @@ constexpr int      JN_SUB     = JN_THREADS * JN_SPT;   // probe tuples per outpu
 constexpr int      JN_CAP     = RJ_JN_CAP;             // LDS table slots (power of two)
 constexpr int      JN_RMAX    = JN_CAP / 2;            // build tuples per table (load <= 50 %)
 constexpr int      JN_RPT     = (JN_RMAX + JN_THREADS - 1) / JN_THREADS;  // build tuples per thread
-// workgroups per CU the LDS table allows (2 words per slot in the common case), and the
-// matching __launch_bounds__ "waves per SIMD" = blocks/CU * threads / 256, capped at 8
-constexpr int      JN_BLOCKS_PER_CU = (160 * 1024) / (JN_CAP * 8 + 1024);
-constexpr int      JN_MIN_WAVES =
-    (JN_BLOCKS_PER_CU * JN_THREADS / 256) > 8 ? 8
-    : ((JN_BLOCKS_PER_CU * JN_THREADS / 256) < 1 ? 1 : (JN_BLOCKS_PER_CU * JN_THREADS / 256));
+// __launch_bounds__ "waves per SIMD" for the join: as many workgroups per CU as the LDS
+// table (table_words arrays of JN_CAP words) allows, times threads / 256, capped at 8
+constexpr int jn_min_waves(int table_words) {
+    int blocks = (160 * 1024) / (JN_CAP * 4 * table_words + JN_CAP + 1024);
+    int w = blocks * JN_THREADS / 256;
+    return w > 8 ? 8 : (w < 1 ? 1 : w);
+}
+static_assert(JN_RPT % 4 == 0 && JN_SPT % 4 == 0, "tuples are loaded as 16-byte vectors");
+#ifndef RJ_JN_PPW
+#define RJ_JN_PPW 1
+#endif
+constexpr int      JN_PPW     = RJ_JN_PPW;             // partitions per workgroup (software pipeline)
 constexpr uint32_t JN_HEAVY   = 32768;                 // probe tuples per task before splitting
 constexpr uint32_t JN_TARGET_BUILD = JN_RMAX * 3 / 4;  // mean build tuples per final partition
 
@@ -141,6 +148,7 @@ struct JoinParams {
     const uint32_t* n_heavy;
     int32_t         heavy_pass;  // 0: one workgroup per partition; 1: heavy task list
     int32_t         pad;
+    unsigned long long* diag;    // phase cycle counters (RJ_DIAG=1 only), else nullptr
 };
 
 }  // namespace rj

@@ -552,8 +552,28 @@ class Exec {
             jp.out_cap = cap;
             jp.heavy_tasks = tasks->as<uint32_t>();
             jp.n_heavy = counters->as<uint32_t>() + 2;
+            BufP diag;
+            if (tune("RJ_DIAG", 0)) {
+                diag = ctx->buf(16 * 8);
+                RJ_HIP(hipMemsetAsync(diag->p, 0, 16 * 8, ctx->stream));
+                jp.diag = diag->as<unsigned long long>();
+            }
             jp.heavy_pass = 0;
-            launch_join(L, KW, bs.CW, ps.CW, jp, PB.NP);
+            launch_join(L, KW, bs.CW, ps.CW, jp, (PB.NP + JN_PPW - 1) / JN_PPW);
+            if (diag) {
+                unsigned long long hd[16];
+                RJ_HIP(hipMemcpyAsync(hd, diag->p, sizeof hd, hipMemcpyDeviceToHost, ctx->stream));
+                ctx->sync();
+                static const char* names[] = {"loads issued", "table clear", "build", "count/probe",
+                                              "prefix+barrier", "reserve", "emit"};
+                double tot = 0;
+                for (int i = 0; i < 7; ++i) tot += (double)hd[i];
+                fprintf(stderr, "[rj diag] join phases (cycles of thread 0, summed over %u workgroups):\n", PB.NP);
+                for (int i = 0; i < 7; ++i)
+                    fprintf(stderr, "[rj diag]   %-16s %6.1f %%  %8.0f cyc/wg\n", names[i],
+                            100.0 * hd[i] / tot, (double)hd[i] / PB.NP);
+                jp.diag = nullptr;
+            }
             jp.heavy_pass = 1;
             launch_join(L, KW, bs.CW, ps.CW, jp, max_tasks);
             unsigned long long h = 0;

@@ -71,6 +71,11 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// 16-byte vector of four tuples' words.  Tuple runs start at arbitrary (4-byte aligned)
+// offsets; gfx950 global loads only need dword alignment, so one dwordx4 replaces four
+// dword loads and their address arithmetic.
+typedef uint32_t u32x4a __attribute__((ext_vector_type(4), aligned(4)));
+
 // Exclusive scan of one value per thread across the workgroup (blockDim.x a
 // multiple of 64, at most 1024).  s_wsum needs blockDim.x/64 words.  Contains
 // one barrier; the caller must sync again before reusing s_wsum.
@@ -575,212 +580,350 @@ __global__ void k_heavy_tasks(const uint32_t* offR, const uint32_t* offS, uint32
 // differ from the partition's, so it cannot collide with a stored hashed key.
 // A build partition larger than JN_RMAX is processed in table-sized chunks
 // (block nested loop), which keeps any duplicate-heavy input correct.
-template <int KW, int CWR, int CWS>
-__global__ __launch_bounds__(JN_THREADS, JN_MIN_WAVES) void k_join(JoinParams jp) {
+// OM (output mode) fixes the stream layout at compile time for the two hot shapes, so the
+// emit code is straight-line stores instead of a per-store mode switch:
+//   OM_PAGED32  key/bc/pc are all INT32 Page images (root of a plan, BASELINE config)
+//   OM_DENSE32  all present streams are dense 32-bit arrays (inner joins, row-index carries)
+//   OM_GENERIC  anything else (64-bit streams, mixed layouts, no key stream)
+enum { OM_GENERIC = 0, OM_PAGED32 = 1, OM_DENSE32 = 2 };
+
+// Diagnostic phase stamps (RJ_DIAG=1): thread 0 of every workgroup adds the cycles between
+// consecutive stamps to jp.diag[phase].  Shares only — the stamps perturb the timing.
+#define RJ_STAMP(PHASE)                                                         \
+    do {                                                                        \
+        if (jp.diag) {                                                          \
+            unsigned long long _t = __builtin_amdgcn_s_memtime();               \
+            if (threadIdx.x == 0) atomicAdd(&jp.diag[PHASE], _t - diag_t);      \
+            diag_t = _t;                                                        \
+        }                                                                       \
+    } while (0)
+
+template <int KW, int CWR, int CWS, int OM>
+__global__ __launch_bounds__(JN_THREADS, jn_min_waves(KW + CWR)) void k_join(JoinParams jp) {
     constexpr int      RW = KW + CWR;  // LDS table arrays (one per word)
     constexpr int      SW = KW + CWS;
-    __shared__ uint32_t t_w[RW][JN_CAP];
+    // Bucketised table: JN_CAP slots = JN_CAP/4 buckets of 4 consecutive slots.  A probe
+    // reads a whole bucket with ONE 16-byte LDS read and compares in registers, an insert
+    // takes its slot from ONE LDS counter atomic — so nearly every lane finishes in a single
+    // iteration and the wave does not pay the longest linear-probing chain of its 64 lanes.
+    // A full bucket (4th slot used) sends probe and insert on to the next bucket.
+    __shared__ __attribute__((aligned(16))) uint32_t t_w[RW][JN_CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t t_cnt[JN_CAP / 4];
     __shared__ uint32_t s_wtot[JN_THREADS / 64];
     __shared__ unsigned long long s_obase;
 
-    uint32_t q, sbeg, send;
-    if (jp.heavy_pass) {
-        if (blockIdx.x >= *jp.n_heavy) return;
-        q = jp.heavy_tasks[3 * blockIdx.x + 0];
-        sbeg = jp.heavy_tasks[3 * blockIdx.x + 1];
-        send = jp.heavy_tasks[3 * blockIdx.x + 2];
-    } else {
-        q = blockIdx.x;
-        if (q >= jp.NP) return;
-        sbeg = jp.offS[q];
-        send = jp.offS[q + 1];
-        if (send - sbeg > JN_HEAVY) return;  // split into tasks by k_heavy_tasks
-    }
-    const uint32_t rbeg = jp.offR[q], rend = jp.offR[q + 1];
-    if (rbeg == rend || sbeg == send) return;
-
-    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
-    // The low radix bits every hashed key of partition q shares, rebuilt from q
-    // (q = ((d1*F2)+d2)*F3+d3, hash low bits = d1 | d2<<b1 | d3<<(b1+b2)); EMPTY differs
-    // from them in bit 0, so no stored key can equal it.
-    uint32_t qbits = 0;
-    {
-        uint32_t rem = q, sh = jp.radix_bits;
-        for (int p = (int)jp.n_pass - 1; p >= 0; --p) {
-            uint32_t b = jp.pass_bits[p];
-            sh -= b;
-            qbits |= (rem & ((1u << b) - 1u)) << sh;
-            rem >>= b;
-        }
-    }
-    const uint32_t EMPTY = qbits ^ 1u;
+    const uint32_t     lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
     constexpr uint32_t SMASK = JN_CAP - 1;
+    constexpr uint32_t BMASK = JN_CAP / 4 - 1;
 
-    for (uint32_t rc = rbeg; rc < rend; rc += JN_RMAX) {
-        const uint32_t rn = min((uint32_t)JN_RMAX, rend - rc);
-        // ---- issue the build loads and the first probe sub-chunk together: one HBM
-        //      latency instead of two, both land while the table is being cleared
-        uint32_t rw[JN_RPT][RW];
+    // A workgroup joins JN_PPW consecutive partitions (main pass) or one heavy task.
+    struct Task {
+        uint32_t q, rbeg, rend, sbeg, send;
+        bool     active;
+    };
+    auto get_task = [&](uint32_t k) {
+        Task t{0, 0, 0, 0, 0, false};
+        if (jp.heavy_pass) {
+            if (k == 0 && blockIdx.x < *jp.n_heavy) {
+                t.q = jp.heavy_tasks[3 * blockIdx.x + 0];
+                t.sbeg = jp.heavy_tasks[3 * blockIdx.x + 1];
+                t.send = jp.heavy_tasks[3 * blockIdx.x + 2];
+                t.rbeg = jp.offR[t.q];
+                t.rend = jp.offR[t.q + 1];
+                t.active = t.rbeg < t.rend && t.sbeg < t.send;
+            }
+            return t;
+        }
+        t.q = blockIdx.x * JN_PPW + k;
+        if (k < JN_PPW && t.q < jp.NP) {
+            t.rbeg = jp.offR[t.q];
+            t.rend = jp.offR[t.q + 1];
+            t.sbeg = jp.offS[t.q];
+            t.send = jp.offS[t.q + 1];
+            // partitions above JN_HEAVY probe tuples are split into tasks (k_heavy_tasks)
+            t.active = t.rbeg < t.rend && t.sbeg < t.send && t.send - t.sbeg <= JN_HEAVY;
+        }
+        return t;
+    };
+
+    // item j of a thread is element ((j/4)*JN_THREADS + tid)*4 + j%4: four consecutive
+    // tuples per 16-byte load
+    uint32_t rw[JN_RPT][RW];
+    uint32_t sw[JN_SPT][SW];
+    auto load_build = [&](uint32_t rc, uint32_t rn) {
 #pragma unroll
-        for (int j = 0; j < JN_RPT; ++j) {
-            uint32_t i = j * JN_THREADS + threadIdx.x;
-            if (i < rn) {
+        for (int v = 0; v < JN_RPT / 4; ++v) {
+            const uint32_t i0 = (v * JN_THREADS + threadIdx.x) * 4;
+            if (i0 + 3 < rn) {
 #pragma unroll
-                for (int a = 0; a < RW; ++a) rw[j][a] = jp.R.w[a][rc + i];
+                for (int a = 0; a < RW; ++a) {
+                    u32x4a x = *reinterpret_cast<const u32x4a*>(jp.R.w[a] + rc + i0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rw[4 * v + e][a] = x[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int a = 0; a < RW; ++a)
+                        rw[4 * v + e][a] = i0 + e < rn ? jp.R.w[a][rc + i0 + e] : 0u;
             }
         }
-        uint32_t sw[JN_SPT][SW];
+    };
+    auto load_probe = [&](uint32_t sc, uint32_t sn) {
+#pragma unroll
+        for (int v = 0; v < JN_SPT / 4; ++v) {
+            const uint32_t i0 = (v * JN_THREADS + threadIdx.x) * 4;
+            if (i0 + 3 < sn) {
+#pragma unroll
+                for (int a = 0; a < SW; ++a) {
+                    u32x4a x = *reinterpret_cast<const u32x4a*>(jp.S.w[a] + sc + i0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sw[4 * v + e][a] = x[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int a = 0; a < SW; ++a)
+                        sw[4 * v + e][a] = i0 + e < sn ? jp.S.w[a][sc + i0 + e] : 0u;
+            }
+        }
+    };
+    // one output row: key + build carry + probe carry
+    auto emit_row = [&](uint64_t row, uint32_t klo, uint32_t khi, uint32_t b0, uint32_t b1,
+                        uint32_t p0, uint32_t p1) {
+        if constexpr (OM == OM_PAGED32) {
+            // one page/slot computation serves all three streams
+            uint32_t r = (uint32_t)row, p = r / ROWS32;
+            size_t   off = (size_t)p * PAGE_BYTES + HDR32 + (r - p * ROWS32) * 4u;
+            *reinterpret_cast<uint32_t*>(jp.key.base + off) = klo;
+            if constexpr (CWR >= 1) *reinterpret_cast<uint32_t*>(jp.bc.base + off) = b0;
+            if constexpr (CWS >= 1) *reinterpret_cast<uint32_t*>(jp.pc.base + off) = p0;
+        } else if constexpr (OM == OM_DENSE32) {
+            reinterpret_cast<uint32_t*>(jp.key.base)[row] = klo;
+            if constexpr (CWR >= 1) reinterpret_cast<uint32_t*>(jp.bc.base)[row] = b0;
+            if constexpr (CWS >= 1) reinterpret_cast<uint32_t*>(jp.pc.base)[row] = p0;
+        } else {
+            stream_store(jp.key, row, klo, khi);
+            if constexpr (CWR >= 1) stream_store(jp.bc, row, b0, b1);
+            if constexpr (CWS >= 1) stream_store(jp.pc, row, p0, p1);
+        }
+    };
+
+    unsigned long long diag_t = jp.diag ? __builtin_amdgcn_s_memtime() : 0ull;
+    const uint32_t     n_tasks = jp.heavy_pass ? 1u : (uint32_t)JN_PPW;
+    Task               cur = get_task(0);
+    // haveR / haveS: the first build chunk / first probe sub-chunk of `cur` already sit in
+    // rw / sw (prefetched while the previous partition was being probed / before its build)
+    bool haveR = false, haveS = false;
+    for (uint32_t k = 0; k < n_tasks; ++k) {
+        const Task nxt = get_task(k + 1);
+        if (!cur.active) {
+            cur = nxt;
+            haveR = haveS = false;
+            continue;
+        }
+        if (!haveR) load_build(cur.rbeg, min((uint32_t)JN_RMAX, cur.rend - cur.rbeg));
+        if (!haveS) load_probe(cur.sbeg, min((uint32_t)JN_SUB, cur.send - cur.sbeg));
+        uint32_t sw_pos = cur.sbeg;  // which probe sub-chunk sw holds
+        RJ_STAMP(0);  // loads issued
+
+        // The low radix bits every hashed key of partition q shares, rebuilt from q
+        // (q = ((d1*F2)+d2)*F3+d3, hash low bits = d1 | d2<<b1 | d3<<(b1+b2)); EMPTY differs
+        // from them in bit 0, so no stored key can equal it.
+        uint32_t qbits = 0;
         {
-            const uint32_t sn0 = min((uint32_t)JN_SUB, send - sbeg);
-#pragma unroll
-            for (int j = 0; j < JN_SPT; ++j) {
-                uint32_t i = j * JN_THREADS + threadIdx.x;
-#pragma unroll
-                for (int a = 0; a < SW; ++a) sw[j][a] = i < sn0 ? jp.S.w[a][sbeg + i] : 0u;
+            uint32_t rem = cur.q, sh = jp.radix_bits;
+            for (int p = (int)jp.n_pass - 1; p >= 0; --p) {
+                uint32_t b = jp.pass_bits[p];
+                sh -= b;
+                qbits |= (rem & ((1u << b) - 1u)) << sh;
+                rem >>= b;
             }
         }
-        for (uint32_t i = threadIdx.x; i < JN_CAP; i += JN_THREADS) t_w[0][i] = EMPTY;
-        lds_barrier();
-        // ---- build
-#pragma unroll
-        for (int j = 0; j < JN_RPT; ++j) {
-            uint32_t i = j * JN_THREADS + threadIdx.x;
-            if (i < rn) {
-                uint32_t slot = (rw[j][0] >> jp.radix_bits) & SMASK;
-                while (true) {
-                    uint32_t old = atomicCAS(&t_w[0][slot], EMPTY, rw[j][0]);
-                    if (old == EMPTY) {
-#pragma unroll
-                        for (int a = 1; a < RW; ++a) t_w[a][slot] = rw[j][a];
-                        break;
-                    }
-                    slot = (slot + 1) & SMASK;
-                }
+        const uint32_t EMPTY = qbits ^ 1u;
+
+        for (uint32_t rc = cur.rbeg; rc < cur.rend; rc += JN_RMAX) {
+            const uint32_t rn = min((uint32_t)JN_RMAX, cur.rend - rc);
+            if (rc != cur.rbeg) load_build(rc, rn);
+            {  // clear the key array, 16 bytes per store
+                const uint4 e4 = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
+                uint4*      t4 = reinterpret_cast<uint4*>(&t_w[0][0]);
+                for (uint32_t i = threadIdx.x; i < JN_CAP / 4; i += JN_THREADS) t4[i] = e4;
+                uint4* c4 = reinterpret_cast<uint4*>(&t_cnt[0]);
+                for (uint32_t i = threadIdx.x; i < JN_CAP / 16; i += JN_THREADS)
+                    c4[i] = make_uint4(0, 0, 0, 0);
             }
-        }
-        lds_barrier();
-        // ---- probe, JN_SUB tuples at a time
-        for (uint32_t sc = sbeg; sc < send; sc += JN_SUB) {
-            const uint32_t sn = min((uint32_t)JN_SUB, send - sc);
-            if (sc != sbeg) {
+            lds_barrier();
+            RJ_STAMP(1);  // table cleared
+            // ---- build
 #pragma unroll
-                for (int j = 0; j < JN_SPT; ++j) {
-                    uint32_t i = j * JN_THREADS + threadIdx.x;
-#pragma unroll
-                    for (int a = 0; a < SW; ++a) sw[j][a] = i < sn ? jp.S.w[a][sc + i] : 0u;
-                }
-            }
-            uint32_t m[JN_SPT], f[JN_SPT];
-            // count matches, remember the first matching slot
-#pragma unroll
-            for (int j = 0; j < JN_SPT; ++j) {
-                uint32_t i = j * JN_THREADS + threadIdx.x;
-                m[j] = 0;
-                f[j] = 0;
-                if (i < sn) {
-                    uint32_t slot = (sw[j][0] >> jp.radix_bits) & SMASK;
+            for (int j = 0; j < JN_RPT; ++j) {
+                uint32_t i = ((j / 4) * JN_THREADS + threadIdx.x) * 4 + (j % 4);
+                if (i < rn) {
+                    uint32_t b = (rw[j][0] >> jp.radix_bits) & BMASK;
                     while (true) {
-                        uint32_t k = t_w[0][slot];
-                        if (k == EMPTY) break;
-                        bool eq = k == sw[j][0];
-                        if (KW == 2) eq = eq && t_w[KW - 1][slot] == sw[j][KW - 1];
-                        if (eq) {
-                            if (m[j] == 0) f[j] = slot;
-                            ++m[j];
+                        uint32_t pos = atomicAdd(&t_cnt[b], 1u);
+                        if (pos < 4) {
+                            const uint32_t slot = b * 4 + pos;
+#pragma unroll
+                            for (int a = 0; a < RW; ++a) t_w[a][slot] = rw[j][a];
+                            break;
                         }
-                        slot = (slot + 1) & SMASK;
+                        b = (b + 1) & BMASK;  // bucket full: overflow to the next one
                     }
                 }
             }
-            // offsets inside the wave: ballot + mbcnt when every lane has <= 1 match
-            // (the PK-FK case), shuffle scan otherwise
-            uint32_t pre[JN_SPT];
-            uint32_t wave_total = 0;
-#pragma unroll
-            for (int j = 0; j < JN_SPT; ++j) {
-                uint32_t tot;
-                if (__ballot(m[j] > 1) == 0) {
-                    uint64_t mk = __ballot(m[j] == 1);
-                    pre[j] = lane_prefix(mk);
-                    tot = (uint32_t)__popcll(mk);
-                } else {
-                    uint32_t incl = m[j];
-#pragma unroll
-                    for (int off = 1; off < 64; off <<= 1) {
-                        uint32_t t = __shfl_up(incl, off);
-                        if (lane >= (uint32_t)off) incl += t;
-                    }
-                    pre[j] = incl - m[j];
-                    tot = __shfl(incl, 63);
+            lds_barrier();
+            RJ_STAMP(2);  // built
+            // rw is dead now: start the NEXT partition's build loads behind this probe
+            const bool last_chunk = rc + JN_RMAX >= cur.rend;
+            if (last_chunk && nxt.active)
+                load_build(nxt.rbeg, min((uint32_t)JN_RMAX, nxt.rend - nxt.rbeg));
+
+            // ---- probe, JN_SUB tuples at a time
+            for (uint32_t sc = cur.sbeg; sc < cur.send; sc += JN_SUB) {
+                const uint32_t sn = min((uint32_t)JN_SUB, cur.send - sc);
+                if (sw_pos != sc) {
+                    load_probe(sc, sn);
+                    sw_pos = sc;
                 }
-                pre[j] += wave_total;
-                wave_total += tot;
-            }
-            if (lane == 0) s_wtot[wid] = wave_total;
-            lds_barrier();
-            if (threadIdx.x == 0) {
-                uint32_t tot = 0;
-                for (int k = 0; k < JN_THREADS / 64; ++k) tot += s_wtot[k];
-#if defined(RJ_ABL_NO_ATOMIC)
-                s_obase = sc;  // timing experiment: rows = probe positions (valid only for PK-FK)
-#elif defined(RJ_ABL_CURSOR_SHARD)
-                s_obase = tot ? atomicAdd(jp.out_cursor + 16 * (blockIdx.x & 7), (unsigned long long)tot) : 0ull;
-#else
-                s_obase = tot ? atomicAdd(jp.out_cursor, (unsigned long long)tot) : 0ull;
-#endif
-            }
-            lds_barrier();
-            const uint64_t gbase = s_obase;
-            uint64_t       obase = gbase;
-            uint32_t       block_total = 0;
-            for (uint32_t k = 0; k < JN_THREADS / 64; ++k) {
-                uint32_t t = s_wtot[k];
-                if (k < wid) obase += t;
-                block_total += t;
-            }
-            // rows beyond the stream capacity are counted but not written; the host
-            // re-runs the join with exact-size buffers (out_cursor = rows needed)
-#if defined(RJ_ABL_NO_STORE)
-            const bool fits = false;
-#else
-            const bool fits = gbase + block_total <= jp.out_cap;
-#endif
-            if (fits) {
+                uint32_t m[JN_SPT], f[JN_SPT];
+                // count matches, remember the first matching slot
 #pragma unroll
                 for (int j = 0; j < JN_SPT; ++j) {
-                    if (m[j] == 0) continue;
-                    uint64_t row = obase + pre[j];
-                    uint32_t klo, khi = 0;
-                    if (KW == 1) {
-                        klo = unfmix32(sw[j][0]);
-                    } else {
-                        uint64_t k = unfmix64((uint64_t)sw[j][0] | ((uint64_t)sw[j][KW - 1] << 32));
-                        klo = (uint32_t)k;
-                        khi = (uint32_t)(k >> 32);
-                    }
-                    uint32_t slot = f[j];
-                    uint32_t left = m[j];
-                    while (left) {
-                        bool eq = t_w[0][slot] == sw[j][0];
-                        if (KW == 2) eq = eq && t_w[KW - 1][slot] == sw[j][KW - 1];
-                        if (eq) {
-                            stream_store(jp.key, row, klo, khi);
-                            if constexpr (CWR >= 1)
-                                stream_store(jp.bc, row, t_w[KW][slot],
-                                             CWR == 2 ? t_w[KW + CWR - 1][slot] : 0u);
-                            if constexpr (CWS >= 1)
-                                stream_store(jp.pc, row, sw[j][KW],
-                                             CWS == 2 ? sw[j][KW + CWS - 1] : 0u);
-                            ++row;
-                            --left;
+                    uint32_t i = ((j / 4) * JN_THREADS + threadIdx.x) * 4 + (j % 4);
+                    m[j] = 0;
+                    f[j] = 0;
+                    if (i < sn) {
+                        uint32_t b = (sw[j][0] >> jp.radix_bits) & BMASK;
+                        while (true) {
+                            const uint4 kv = *reinterpret_cast<const uint4*>(&t_w[0][b * 4]);
+                            uint32_t    eq = (uint32_t)(kv.x == sw[j][0]) | ((uint32_t)(kv.y == sw[j][0]) << 1) |
+                                          ((uint32_t)(kv.z == sw[j][0]) << 2) | ((uint32_t)(kv.w == sw[j][0]) << 3);
+                            if (KW == 2 && eq) {
+                                const uint4 hv = *reinterpret_cast<const uint4*>(&t_w[KW - 1][b * 4]);
+                                eq &= (uint32_t)(hv.x == sw[j][KW - 1]) | ((uint32_t)(hv.y == sw[j][KW - 1]) << 1) |
+                                      ((uint32_t)(hv.z == sw[j][KW - 1]) << 2) | ((uint32_t)(hv.w == sw[j][KW - 1]) << 3);
+                            }
+                            if (eq) {
+                                if (m[j] == 0) f[j] = b * 4 + (uint32_t)__builtin_ctz(eq);
+                                m[j] += (uint32_t)__popc(eq);
+                            }
+                            if (kv.w == EMPTY) break;  // bucket not full: nothing overflowed
+                            b = (b + 1) & BMASK;
                         }
-                        slot = (slot + 1) & SMASK;
                     }
                 }
+                RJ_STAMP(3);  // counted
+                // offsets inside the wave: ballot + mbcnt when every lane has <= 1 match
+                // (the PK-FK case), shuffle scan otherwise
+                uint32_t pre[JN_SPT];
+                uint32_t wave_total = 0;
+#pragma unroll
+                for (int j = 0; j < JN_SPT; ++j) {
+                    uint32_t tot;
+                    if (__ballot(m[j] > 1) == 0) {
+                        uint64_t mk = __ballot(m[j] == 1);
+                        pre[j] = lane_prefix(mk);
+                        tot = (uint32_t)__popcll(mk);
+                    } else {
+                        uint32_t incl = m[j];
+#pragma unroll
+                        for (int off = 1; off < 64; off <<= 1) {
+                            uint32_t t = __shfl_up(incl, off);
+                            if (lane >= (uint32_t)off) incl += t;
+                        }
+                        pre[j] = incl - m[j];
+                        tot = __shfl(incl, 63);
+                    }
+                    pre[j] += wave_total;
+                    wave_total += tot;
+                }
+                if (lane == 0) s_wtot[wid] = wave_total;
+                lds_barrier();
+                RJ_STAMP(4);  // wave prefixes + barrier
+                if (threadIdx.x == 0) {
+                    uint32_t tot = 0;
+                    for (int w = 0; w < JN_THREADS / 64; ++w) tot += s_wtot[w];
+#if defined(RJ_ABL_NO_ATOMIC)
+                    s_obase = sc;  // timing experiment: rows = probe positions (PK-FK only)
+#elif defined(RJ_ABL_CURSOR_SHARD)
+                    s_obase = tot ? atomicAdd(jp.out_cursor + 16 * (blockIdx.x & 7), (unsigned long long)tot) : 0ull;
+#else
+                    s_obase = tot ? atomicAdd(jp.out_cursor, (unsigned long long)tot) : 0ull;
+#endif
+                }
+                lds_barrier();
+                RJ_STAMP(5);  // output reservation
+                const uint64_t gbase = s_obase;
+                uint64_t       obase = gbase;
+                uint32_t       block_total = 0;
+                for (uint32_t w = 0; w < JN_THREADS / 64; ++w) {
+                    uint32_t t = s_wtot[w];
+                    if (w < wid) obase += t;
+                    block_total += t;
+                }
+                // rows beyond the stream capacity are counted but not written; the host
+                // re-runs the join with exact-size buffers (out_cursor = rows needed)
+#if defined(RJ_ABL_NO_STORE)
+                const bool fits = false;
+#else
+                const bool fits = gbase + block_total <= jp.out_cap;
+#endif
+                if (fits) {
+                    // the build carry of a tuple's FIRST match sits at the remembered slot
+                    // f[j]: issue those reads for all tuples before the first store
+                    uint32_t c0[JN_SPT], c1[JN_SPT];
+#pragma unroll
+                    for (int j = 0; j < JN_SPT; ++j) {
+                        c0[j] = 0;
+                        c1[j] = 0;
+                        if constexpr (CWR >= 1) c0[j] = m[j] ? t_w[KW][f[j]] : 0u;
+                        if constexpr (CWR == 2) c1[j] = m[j] ? t_w[KW + 1][f[j]] : 0u;
+                    }
+#pragma unroll
+                    for (int j = 0; j < JN_SPT; ++j) {
+                        if (m[j] == 0) continue;
+                        uint64_t row = obase + pre[j];
+                        uint32_t klo, khi = 0;
+                        if (KW == 1) {
+                            klo = unfmix32(sw[j][0]);
+                        } else {
+                            uint64_t k64 =
+                                unfmix64((uint64_t)sw[j][0] | ((uint64_t)sw[j][KW - 1] << 32));
+                            klo = (uint32_t)k64;
+                            khi = (uint32_t)(k64 >> 32);
+                        }
+                        const uint32_t p0 = CWS >= 1 ? sw[j][KW < SW ? KW : 0] : 0u;
+                        const uint32_t p1 = CWS == 2 ? sw[j][SW - 1] : 0u;
+                        emit_row(row, klo, khi, c0[j], c1[j], p0, p1);
+                        // duplicates of the build key occupy further slots of the same run
+                        uint32_t left = m[j] - 1;
+                        uint32_t slot = (f[j] + 1) & SMASK;
+                        while (left) {
+                            bool eq = t_w[0][slot] == sw[j][0];
+                            if (KW == 2) eq = eq && t_w[KW - 1][slot] == sw[j][KW - 1];
+                            if (eq) {
+                                ++row;
+                                emit_row(row, klo, khi, CWR >= 1 ? t_w[KW < RW ? KW : 0][slot] : 0u,
+                                         CWR == 2 ? t_w[RW - 1][slot] : 0u, p0, p1);
+                                --left;
+                            }
+                            slot = (slot + 1) & SMASK;
+                        }
+                    }
+                }
+                RJ_STAMP(6);  // emitted
+                lds_barrier();  // s_wtot / s_obase are reused by the next sub-chunk
             }
-            lds_barrier();  // s_wtot / s_obase are reused by the next sub-chunk
+            lds_barrier();  // table is cleared for the next build chunk
         }
-        lds_barrier();  // table is cleared for the next build chunk
+        // sw is dead now: start the next partition's probe loads behind its table build
+        if (nxt.active) load_probe(nxt.sbeg, min((uint32_t)JN_SUB, nxt.send - nxt.sbeg));
+        haveR = haveS = nxt.active;
+        cur = nxt;
     }
 }
 
@@ -999,8 +1142,28 @@ void launch_heavy_tasks(const Launch& L, const uint32_t* offR, const uint32_t* o
 
 template <int KW, int CWR, int CWS>
 static void join_t(const Launch& L, const JoinParams& jp, uint32_t grid) {
-    RJ_KLAUNCH(L, jp.heavy_pass ? "join_heavy" : "join_build_probe", (k_join<KW, CWR, CWS>), grid,
-               JN_THREADS, jp);
+    const char* name = jp.heavy_pass ? "join_heavy" : "join_build_probe";
+    // pick the straight-line emit variant when the stream layout allows it
+    int om = OM_GENERIC;
+    if (KW == 1 && CWR <= 1 && CWS <= 1) {
+        auto all = [&](int mode) {
+            return jp.key.mode == mode && (CWR == 0 || jp.bc.mode == mode) &&
+                   (CWS == 0 || jp.pc.mode == mode);
+        };
+        if (all(ST_PAGED32)) om = OM_PAGED32;
+        if (all(ST_DENSE32)) om = OM_DENSE32;
+    }
+    if constexpr (KW == 1 && CWR <= 1 && CWS <= 1) {
+        if (om == OM_PAGED32) {
+            RJ_KLAUNCH(L, name, (k_join<KW, CWR, CWS, OM_PAGED32>), grid, JN_THREADS, jp);
+            return;
+        }
+        if (om == OM_DENSE32) {
+            RJ_KLAUNCH(L, name, (k_join<KW, CWR, CWS, OM_DENSE32>), grid, JN_THREADS, jp);
+            return;
+        }
+    }
+    RJ_KLAUNCH(L, name, (k_join<KW, CWR, CWS, OM_GENERIC>), grid, JN_THREADS, jp);
 }
 
 void launch_join(const Launch& L, int key_words, int cw_build, int cw_probe, const JoinParams& jp,
