@@ -263,6 +263,16 @@ struct DenseLoader {
     Words in;
     __device__ __forceinline__ uint32_t key_tile(uint32_t base, uint32_t end,
                                                  uint32_t (&hk)[PT_ITEMS]) const {
+        if (base + PT_TILE <= end) {  // full tile: four consecutive tuples per 16-byte load
+#pragma unroll
+            for (int v = 0; v < PT_ITEMS / 4; ++v) {
+                u32x4a x = *reinterpret_cast<const u32x4a*>(in.w[0] + base +
+                                                            (v * PT_THREADS + threadIdx.x) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hk[4 * v + e] = x[e];
+            }
+            return (1u << PT_ITEMS) - 1u;
+        }
         uint32_t ok = 0;
 #pragma unroll
         for (int j = 0; j < PT_ITEMS; ++j) {
@@ -275,6 +285,19 @@ struct DenseLoader {
     template <int NW>
     __device__ __forceinline__ uint32_t load_tile(uint32_t base, uint32_t end,
                                                   uint32_t (&w)[PT_ITEMS][NW]) const {
+        if (base + PT_TILE <= end) {
+#pragma unroll
+            for (int v = 0; v < PT_ITEMS / 4; ++v) {
+                const uint32_t i0 = base + (v * PT_THREADS + threadIdx.x) * 4;
+#pragma unroll
+                for (int a = 0; a < NW; ++a) {
+                    u32x4a x = *reinterpret_cast<const u32x4a*>(in.w[a] + i0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[4 * v + e][a] = x[e];
+                }
+            }
+            return (1u << PT_ITEMS) - 1u;
+        }
         uint32_t ok = 0;
 #pragma unroll
         for (int j = 0; j < PT_ITEMS; ++j) {
@@ -307,37 +330,74 @@ template <int KW, int CW>
 struct SrcLoader {
     TupleSrc s;
 
-    // raw key words of the tile + validity mask
-    __device__ __forceinline__ uint32_t raw_keys(uint32_t base, uint32_t end,
-                                                 uint32_t (&lo)[PT_ITEMS],
-                                                 uint32_t (&hi)[PT_ITEMS]) const {
-        const bool     paged = s.key.kind == COL_PAGED;
-        const uint8_t* kp = s.key.ptr;
-        uint32_t       ok = 0;
+    // Row of item j.  Full tiles use the vector mapping (four consecutive rows per thread
+    // and 16-byte load; ROWS32 % 4 == 0 and tiles start at multiples of 4, so the four rows
+    // share a page), partial tiles the strided one with clamped indices.
+    __device__ __forceinline__ static uint32_t item_row(bool vec, uint32_t base, int j) {
+        return vec ? base + ((j / 4) * PT_THREADS + threadIdx.x) * 4 + (j % 4)
+                   : base + j * PT_THREADS + threadIdx.x;
+    }
+
+    // 32-bit column -> one word per item
+    __device__ __forceinline__ static void load_col32(const ColRef& c, bool vec, uint32_t base,
+                                                      uint32_t end, uint32_t (&out)[PT_ITEMS]) {
+        const bool     paged = c.kind == COL_PAGED;
+        const uint8_t* p = c.ptr;
+        if (vec) {
+#pragma unroll
+            for (int v = 0; v < PT_ITEMS / 4; ++v) {
+                const uint32_t r0 = base + (v * PT_THREADS + threadIdx.x) * 4;
+                u32x4a x = *reinterpret_cast<const u32x4a*>(p + col_off32(paged, r0));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) out[4 * v + e] = x[e];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PT_ITEMS; ++j) {
+                const uint32_t ic = min(base + j * PT_THREADS + threadIdx.x, end - 1u);
+                out[j] = *reinterpret_cast<const uint32_t*>(p + col_off32(paged, ic));
+            }
+        }
+    }
+    __device__ __forceinline__ static void load_col64(const ColRef& c, bool vec, uint32_t base,
+                                                      uint32_t end, uint32_t (&lo)[PT_ITEMS],
+                                                      uint32_t (&hi)[PT_ITEMS]) {
+        const bool     paged = c.kind == COL_PAGED;
+        const uint8_t* p = c.ptr;
 #pragma unroll
         for (int j = 0; j < PT_ITEMS; ++j) {
-            uint32_t i = base + j * PT_THREADS + threadIdx.x;
-            uint32_t ic = min(i, end - 1u);
-            if constexpr (KW == 1) {
-                lo[j] = *reinterpret_cast<const uint32_t*>(kp + col_off32(paged, ic));
-                hi[j] = 0;
-            } else {
-                uint64_t k = *reinterpret_cast<const uint64_t*>(kp + col_off64(paged, ic));
-                lo[j] = (uint32_t)k;
-                hi[j] = (uint32_t)(k >> 32);
-            }
-            ok |= (uint32_t)(i < end) << j;
+            const uint32_t ic = min(item_row(vec, base, j), end - 1u);
+            uint64_t       v = *reinterpret_cast<const uint64_t*>(p + col_off64(paged, ic));
+            lo[j] = (uint32_t)v;
+            hi[j] = (uint32_t)(v >> 32);
         }
+    }
+
+    // raw key words of the tile + in-range mask
+    __device__ __forceinline__ uint32_t raw_keys(bool vec, uint32_t base, uint32_t end,
+                                                 uint32_t (&lo)[PT_ITEMS],
+                                                 uint32_t (&hi)[PT_ITEMS]) const {
+        if constexpr (KW == 1) {
+            load_col32(s.key, vec, base, end, lo);
+#pragma unroll
+            for (int j = 0; j < PT_ITEMS; ++j) hi[j] = 0;
+        } else {
+            load_col64(s.key, vec, base, end, lo, hi);
+        }
+        if (vec) return (1u << PT_ITEMS) - 1u;
+        uint32_t ok = 0;
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS; ++j)
+            ok |= (uint32_t)(base + j * PT_THREADS + threadIdx.x < end) << j;
         return ok;
     }
-    __device__ __forceinline__ uint32_t drop_invalid(uint32_t base, uint32_t end, uint32_t ok) const {
+    __device__ __forceinline__ uint32_t drop_invalid(bool vec, uint32_t base, uint32_t end,
+                                                     uint32_t ok) const {
         const uint8_t* vp = s.key.valid;
         if (vp) {  // uniform: the column was decoded by K1 and carries validity bytes
 #pragma unroll
-            for (int j = 0; j < PT_ITEMS; ++j) {
-                uint32_t i = base + j * PT_THREADS + threadIdx.x;
-                if (!vp[min(i, end - 1u)]) ok &= ~(1u << j);
-            }
+            for (int j = 0; j < PT_ITEMS; ++j)
+                if (!vp[min(item_row(vec, base, j), end - 1u)]) ok &= ~(1u << j);
         }
         return ok;
     }
@@ -366,38 +426,39 @@ struct SrcLoader {
     }
     __device__ __forceinline__ uint32_t key_tile(uint32_t base, uint32_t end,
                                                  uint32_t (&hk)[PT_ITEMS]) const {
-        uint32_t hi[PT_ITEMS];
-        uint32_t ok = raw_keys(base, end, hk, hi);
-        ok = drop_invalid(base, end, ok);
+        const bool vec = base + PT_TILE <= end;
+        uint32_t   hi[PT_ITEMS];
+        uint32_t   ok = raw_keys(vec, base, end, hk, hi);
+        ok = drop_invalid(vec, base, end, ok);
         return hash_keys(ok, hk, hi);
     }
     template <int NW>
     __device__ __forceinline__ uint32_t load_tile(uint32_t base, uint32_t end,
                                                   uint32_t (&w)[PT_ITEMS][NW]) const {
         static_assert(NW == KW + CW, "word count");
-        uint32_t lo[PT_ITEMS], hi[PT_ITEMS];
-        uint32_t ok = raw_keys(base, end, lo, hi);
+        const bool vec = base + PT_TILE <= end;
+        uint32_t   lo[PT_ITEMS], hi[PT_ITEMS];
+        uint32_t   ok = raw_keys(vec, base, end, lo, hi);
         if constexpr (CW >= 1) {
             if (s.carry_mode == CARRY_ROWIDX) {  // CW == 1 by construction
 #pragma unroll
-                for (int j = 0; j < PT_ITEMS; ++j) w[j][KW] = base + j * PT_THREADS + threadIdx.x;
+                for (int j = 0; j < PT_ITEMS; ++j) w[j][KW] = item_row(vec, base, j);
+            } else if constexpr (CW == 1) {
+                uint32_t c0[PT_ITEMS];
+                load_col32(s.carry, vec, base, end, c0);
+#pragma unroll
+                for (int j = 0; j < PT_ITEMS; ++j) w[j][KW] = c0[j];
             } else {
-                const bool     paged = s.carry.kind == COL_PAGED;
-                const uint8_t* cp = s.carry.ptr;
+                uint32_t c0[PT_ITEMS], c1[PT_ITEMS];
+                load_col64(s.carry, vec, base, end, c0, c1);
 #pragma unroll
                 for (int j = 0; j < PT_ITEMS; ++j) {
-                    uint32_t ic = min(base + j * PT_THREADS + threadIdx.x, end - 1u);
-                    if constexpr (CW == 1) {
-                        w[j][KW] = *reinterpret_cast<const uint32_t*>(cp + col_off32(paged, ic));
-                    } else {
-                        uint64_t v = *reinterpret_cast<const uint64_t*>(cp + col_off64(paged, ic));
-                        w[j][KW] = (uint32_t)v;
-                        w[j][KW + 1] = (uint32_t)(v >> 32);
-                    }
+                    w[j][KW] = c0[j];
+                    w[j][KW + 1] = c1[j];
                 }
             }
         }
-        ok = drop_invalid(base, end, ok);
+        ok = drop_invalid(vec, base, end, ok);
         ok = hash_keys(ok, lo, hi);
 #pragma unroll
         for (int j = 0; j < PT_ITEMS; ++j) {
@@ -477,7 +538,6 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_hist(Loader ld, PassParams 
 template <int NW, class Loader>
 __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassParams pp, Words out) {
     __shared__ uint32_t s_stage[PT_TILE];
-    __shared__ uint16_t s_dig[PT_TILE];
     __shared__ uint32_t s_cnt[PT_MAXF];
     __shared__ uint32_t s_base[PT_MAXF];
     __shared__ uint32_t s_delta[PT_MAXF];
@@ -524,21 +584,42 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassPara
         }
         lds_barrier();
 
+        // LDS position of every tuple, computed once for all word arrays
 #pragma unroll
-        for (int a = 0; a < NW; ++a) {
+        for (int j = 0; j < PT_ITEMS; ++j)
+            if (dr[j] != 0xffffffffu) dr[j] = s_base[dr[j] >> 16] + (dr[j] & 0xffffu);
+
+        // word 0 (the hashed key): stage in digit order, copy out.  The digit of a staged
+        // key is recomputed from the key itself, and the global destination of each LDS
+        // position is kept in a register for the remaining word arrays.
 #pragma unroll
-            for (int j = 0; j < PT_ITEMS; ++j) {
-                if (dr[j] != 0xffffffffu) {
-                    uint32_t d = dr[j] >> 16;
-                    uint32_t pos = s_base[d] + (dr[j] & 0xffffu);
-                    s_stage[pos] = w[j][a];
-                    if (a == 0) s_dig[pos] = (uint16_t)d;
-                }
+        for (int j = 0; j < PT_ITEMS; ++j)
+            if (dr[j] != 0xffffffffu) s_stage[dr[j]] = w[j][0];
+        lds_barrier();
+        uint32_t dest[PT_ITEMS];
+#pragma unroll
+        for (int k = 0; k < PT_ITEMS; ++k) {
+            const uint32_t i = k * PT_THREADS + threadIdx.x;
+            dest[k] = 0;
+            if (i < total) {
+                const uint32_t v = s_stage[i];
+                dest[k] = s_delta[(v >> pp.shift) & mask] + i;
+                out.w[0][dest[k]] = v;
             }
+        }
+        lds_barrier();
+#pragma unroll
+        for (int a = 1; a < NW; ++a) {
+#pragma unroll
+            for (int j = 0; j < PT_ITEMS; ++j)
+                if (dr[j] != 0xffffffffu) s_stage[dr[j]] = w[j][a];
             lds_barrier();
             uint32_t* dst = out.w[a];
-            for (uint32_t i = threadIdx.x; i < total; i += PT_THREADS)
-                dst[s_delta[s_dig[i]] + i] = s_stage[i];
+#pragma unroll
+            for (int k = 0; k < PT_ITEMS; ++k) {
+                const uint32_t i = k * PT_THREADS + threadIdx.x;
+                if (i < total) dst[dest[k]] = s_stage[i];
+            }
             lds_barrier();
         }
     }

@@ -65,3 +65,24 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def pmc_table(d, sub, counters):
+    """mean per-dispatch value of each counter for the full-size launches of every rj:: kernel"""
+    import statistics
+    acc = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(d, sub, "**", "*_counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            s = short(r["Kernel_Name"])
+            if s:
+                acc[s][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    rows = []
+    for k, cs in acc.items():
+        row = [k]
+        for c in counters:
+            v = cs.get(c, [])
+            # the largest values belong to the full-size launches
+            v = sorted(v)[-max(1, len(v) // 2):] if v else [0]
+            row.append(statistics.mean(v))
+        rows.append(row)
+    return rows
