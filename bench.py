@@ -185,16 +185,23 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path is the product, there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # RJ_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks
+    # (ranks share devices, the exchange is staged through the host); the default is RCCL.
+    backend = os.environ.get("RJ_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if distributed:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     n = args.rows
-    ctx = capi.Context(device=local_rank, profile=True)
+    ctx = capi.Context(device=dev_index, profile=True)
     rk, rp, sk, sp = make_relations(n, rank, world, device)
     R = adopt(ctx, [rk, rp])
     S = adopt(ctx, [sk, sp])
@@ -240,10 +247,11 @@ def main():
 
     total_rows = rows
     if distributed:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        rdev = device if backend == "nccl" else torch.device("cpu")
+        tt = torch.tensor([dt], dtype=torch.float64, device=rdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        tr = torch.tensor([rows], dtype=torch.int64, device=device)
+        tr = torch.tensor([rows], dtype=torch.int64, device=rdev)
         dist.all_reduce(tr, op=dist.ReduceOp.SUM)
         total_rows = int(tr.item())
     # every probe key hits exactly one build row: |out| = |S|
@@ -269,7 +277,7 @@ def main():
                 "workload": f"single JoinNode, {n} x {n} INT32 uniform keys per GPU (build = permutation, probe = iid), "
                 "1 INT32 payload col per side, Page-packed inputs resident in HBM, Page-encoded output in HBM",
                 "rows_per_relation_per_gpu": n,
-                "parallelism": "single GPU" if world == 1 else f"hash-sharded x{world}, one RCCL all-to-all",
+                "parallelism": "single GPU" if world == 1 else f"hash-sharded x{world}, one all-to-all ({backend})",
                 "device": info["name"],
                 "arch": info["arch"],
             },

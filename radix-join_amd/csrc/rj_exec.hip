@@ -474,6 +474,12 @@ class Exec {
         uint32_t bits = js.forced_bits > 0
                             ? (uint32_t)js.forced_bits
                             : ceil_log2((bs.rel->n + JN_TARGET_BUILD - 1) / JN_TARGET_BUILD);
+        // a third pass costs 20 B/tuple more than slightly fuller tables: stay at two passes
+        // (2 * PT_MAXBITS bits) while the mean build partition still fits the LDS table with
+        // a margin (rare larger partitions are joined in table-sized chunks anyway)
+        if (js.forced_bits <= 0 && bits > 2 * PT_MAXBITS &&
+            (bs.rel->n >> (2 * PT_MAXBITS)) <= (uint64_t)(JN_RMAX * 0.95))
+            bits = 2 * PT_MAXBITS;
         bits = std::min<uint32_t>(std::max<uint32_t>(bits, 1), 27);
 
         auto make_src = [&](Side& s) {

@@ -69,11 +69,24 @@ class ShardedJoin:
     def _exchange(self, key, carry, counts):
         t, d = self.torch, self.dist
         dev = key.device
-        send = t.tensor(counts, dtype=t.int64, device=dev)
+        # RCCL moves device tensors directly over xGMI; gloo (CPU tests, and the one-GPU
+        # rehearsal of the multi-rank bench) needs host tensors, so stage through the host
+        host = d.get_backend(self.group) == "gloo" and dev.type != "cpu"
+        cdev = t.device("cpu") if host else dev
+        send = t.tensor(counts, dtype=t.int64, device=cdev)
         recv = t.empty_like(send)
         d.all_to_all_single(recv, send, group=self.group)
         rc = [int(x) for x in recv.tolist()]
-        rkey, rcarry = self.ops.empty(sum(rc)), self.ops.empty(sum(rc))
+        n = sum(rc)
+        if host:
+            rkey_h, rcarry_h = t.empty(n, dtype=key.dtype), t.empty(n, dtype=carry.dtype)
+            d.all_to_all_single(rkey_h, key.cpu(), output_split_sizes=rc, input_split_sizes=list(counts), group=self.group)
+            d.all_to_all_single(rcarry_h, carry.cpu(), output_split_sizes=rc, input_split_sizes=list(counts), group=self.group)
+            rkey, rcarry = self.ops.empty(n), self.ops.empty(n)
+            rkey.copy_(rkey_h)
+            rcarry.copy_(rcarry_h)
+            return rkey, rcarry
+        rkey, rcarry = self.ops.empty(n), self.ops.empty(n)
         d.all_to_all_single(rkey, key, output_split_sizes=rc, input_split_sizes=list(counts), group=self.group)
         d.all_to_all_single(rcarry, carry, output_split_sizes=rc, input_split_sizes=list(counts), group=self.group)
         return rkey, rcarry
