@@ -153,6 +153,16 @@ def roofline(stats, rows_build, rows_probe, steps_profiled):
         tuples = (rows_build + rows_probe) / 2.0
     algo = ALGO_BYTES[name] * tuples
     achieved = algo / (avg_ms * 1e-3) / 1e9
+    # HBM bytes per launch from the PMC passes committed under profiles/ (bench.py cannot
+    # collect hardware counters itself); only valid for the size they were collected at
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic_r01.json")) as f:
+            t = json.load(f)
+        if t["rows_per_relation"] == rows_probe == rows_build:
+            traffic = t["bytes_per_launch"].get(name)
+    except Exception:
+        traffic = None
     return {
         "kernel": name,
         "bound": "hbm",
@@ -160,7 +170,8 @@ def roofline(stats, rows_build, rows_probe, steps_profiled):
         "peak": HBM_PEAK_GBPS,
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBPS,
-        "traffic": None,
+        "traffic": traffic,
+        "traffic_source": "profiles/traffic_r01.json (rocprofv3 PMC, gfx950-corrected)" if traffic else None,
         "avg_launch_ms": avg_ms,
         "algorithmic_bytes_per_launch": algo,
         "kernels_ms_per_step": {s["name"]: s["total_ms"] / steps_profiled for s in stats},
