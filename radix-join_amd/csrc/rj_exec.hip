@@ -502,7 +502,7 @@ class Exec {
         // heavy probe partitions -> task list
         uint32_t max_tasks = (uint32_t)(2 * (ps.rel->n / JN_HEAVY) + 2);
         BufP     tasks = ctx->buf((uint64_t)max_tasks * 12);
-        BufP     counters = ctx->buf(2048);  // [0..7] out cursor (u64), [8..11] n_heavy
+        BufP     counters = ctx->buf(16);  // [0..7] out cursor (u64), [8..11] n_heavy
         launch_heavy_tasks_zeroed(PB, PP, tasks, counters, max_tasks);
 
         // stream destinations
@@ -541,7 +541,6 @@ class Exec {
                 s->stream = s->stream_mode != ST_NONE ? ctx->buf(stream_bytes(s->stream_mode, cap))
                                                       : BufP();
             RJ_HIP(hipMemsetAsync(counters->p, 0, 8, ctx->stream));
-            RJ_HIP(hipMemsetAsync(counters->as<uint8_t>() + 16, 0, 2048 - 16, ctx->stream));
             JoinParams jp{};
             jp.R = PB.w;
             jp.S = PP.w;

@@ -928,13 +928,7 @@ __global__ __launch_bounds__(JN_THREADS, jn_min_waves(KW + CWR)) void k_join(Joi
                 if (threadIdx.x == 0) {
                     uint32_t tot = 0;
                     for (int w = 0; w < JN_THREADS / 64; ++w) tot += s_wtot[w];
-#if defined(RJ_ABL_NO_ATOMIC)
-                    s_obase = sc;  // timing experiment: rows = probe positions (PK-FK only)
-#elif defined(RJ_ABL_CURSOR_SHARD)
-                    s_obase = tot ? atomicAdd(jp.out_cursor + 16 * (blockIdx.x & 7), (unsigned long long)tot) : 0ull;
-#else
                     s_obase = tot ? atomicAdd(jp.out_cursor, (unsigned long long)tot) : 0ull;
-#endif
                 }
                 lds_barrier();
                 RJ_STAMP(5);  // output reservation
@@ -948,11 +942,7 @@ __global__ __launch_bounds__(JN_THREADS, jn_min_waves(KW + CWR)) void k_join(Joi
                 }
                 // rows beyond the stream capacity are counted but not written; the host
                 // re-runs the join with exact-size buffers (out_cursor = rows needed)
-#if defined(RJ_ABL_NO_STORE)
-                const bool fits = false;
-#else
                 const bool fits = gbase + block_total <= jp.out_cap;
-#endif
                 if (fits) {
                     // the build carry of a tuple's FIRST match sits at the remembered slot
                     // f[j]: issue those reads for all tuples before the first store
