@@ -138,11 +138,27 @@ int rj_execute(rj_context* ctx, const rj_plan* plan, rj_result** out) {
                     throw rj::Error(RJ_ERR_ARG, "scan: bad base_table_id");
                 used[plan->nodes[i].base_table_id] = true;
             }
+        // ... and of those only the columns a ScanNode outputs (the harness hands over every
+        // column of a scanned base table, reference tests/read_sql.cpp:1100-1107; the reference
+        // decodes them all, src/build_table.cpp:317-434)
+        std::vector<std::vector<bool>> col_used(plan->n_inputs);
+        for (uint64_t i = 0; i < plan->n_inputs; ++i)
+            col_used[i].assign(plan->inputs[i].n_cols, false);
+        for (uint64_t i = 0; i < plan->n_nodes; ++i) {
+            const rj_node& nd = plan->nodes[i];
+            if (nd.kind != RJ_NODE_SCAN) continue;
+            for (uint64_t k = 0; k < nd.n_out; ++k) {
+                if (nd.out_idx[k] >= col_used[nd.base_table_id].size())
+                    throw rj::Error(RJ_ERR_ARG, "scan: output attr out of range");
+                col_used[nd.base_table_id][nd.out_idx[k]] = true;
+            }
+        }
         std::vector<std::unique_ptr<Table>> owned(plan->n_inputs);
         std::vector<Table*>                 ts(plan->n_inputs, nullptr);
         rj_input                            none{};
         for (uint64_t i = 0; i < plan->n_inputs; ++i) {
-            owned[i].reset(table_upload(ctx, used[i] ? &plan->inputs[i] : &none));
+            owned[i].reset(table_upload(ctx, used[i] ? &plan->inputs[i] : &none,
+                                        used[i] ? &col_used[i] : nullptr, /*borrow_varchar=*/true));
             ts[i] = owned[i].get();
         }
         *out = static_cast<rj_result*>(execute_plan(ctx, plan, ts.data(), plan->n_inputs, 0));

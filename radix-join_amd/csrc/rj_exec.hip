@@ -161,6 +161,7 @@ class Exec {
     // ------------------------------------------------------------- scan side
     DCol table_col(const Table* t, int c) {
         const TableColumn& tc = t->cols[c];
+        if (tc.skipped) throw_fmt(RJ_ERR_ARG, "column was not uploaded (not referenced by a scan)");
         DCol               d;
         d.type = tc.type;
         d.tcol = &tc;
@@ -237,9 +238,12 @@ class Exec {
             ResultColumn rc;
             rc.type = tc.type;
             rc.n_pages = tc.n_pages;
+            if (tc.skipped) throw_fmt(RJ_ERR_ARG, "column was not uploaded");
             if (tc.type == RJ_VARCHAR) {
-                rc.host_pages = tc.host_pages;
-                rc.n_pages = tc.host_pages.size() / PAGE_BYTES;
+                rc.n_pages = tc.vc_pages.size();
+                rc.host_pages.resize(rc.n_pages * PAGE_BYTES);
+                for (uint64_t pg = 0; pg < rc.n_pages; ++pg)
+                    memcpy(rc.host_pages.data() + pg * PAGE_BYTES, tc.vc_pages[pg], PAGE_BYTES);
             } else if (tc.n_pages) {
                 rc.dev_pages = ctx->buf(tc.n_pages * PAGE_BYTES);
                 RJ_HIP(hipMemcpyAsync(rc.dev_pages->p, tc.dev_pages, tc.n_pages * PAGE_BYTES,
@@ -702,7 +706,7 @@ class Exec {
         if (it == vc_index_.end()) {
             it = vc_index_.emplace(key, std::make_pair(std::vector<StrView>(), std::vector<std::string>()))
                      .first;
-            varchar_index(tc.host_pages.data(), tc.host_pages.size() / PAGE_BYTES, t->num_rows,
+            varchar_index(tc.vc_pages.data(), tc.vc_pages.size(), t->num_rows,
                           it->second.first, it->second.second);
         }
         varchar_gather_encode(it->second.first, ids.data(), n, rc.host_pages, rc.n_pages);

@@ -119,8 +119,12 @@ struct TableColumn {
     bool           regular = false; // addressable in place (see ColKind::COL_PAGED)
     uint64_t       page_rows_total = 0;
     BufP           page_rows;      // u32[n_pages] rows per page (for K1)
-    // VARCHAR columns: host page images (a private copy)
-    std::vector<uint8_t> host_pages;
+    // VARCHAR columns stay on the host: vc_pages[i] points at page i — into `host_pages`
+    // (a private copy, resident tables) or into the caller's pages (rj_execute, where the
+    // Plan's inputs outlive the call)
+    std::vector<uint8_t>        host_pages;
+    std::vector<const uint8_t*> vc_pages;
+    bool                        skipped = false;  // not referenced by the plan: never uploaded
 };
 
 struct Table {
@@ -181,7 +185,10 @@ void    shard_partition(Context* ctx, const Table* t, uint64_t key_col, uint64_t
                         uint32_t n_ranks, rj_tuples* out, uint64_t* counts);
 
 // rj_table.hip
-Table* table_upload(Context* ctx, const rj_input* host);
+// col_used: upload only these columns (nullptr = all); borrow_varchar: keep pointers to the
+// caller's VARCHAR pages instead of copying them
+Table* table_upload(Context* ctx, const rj_input* host, const std::vector<bool>* col_used = nullptr,
+                    bool borrow_varchar = false);
 Table* table_adopt(Context* ctx, uint64_t num_rows, uint64_t n_cols, const int32_t* types,
                    const void* const* dev_pages, const uint64_t* n_pages);
 void   result_copy_pages(Result* r, uint64_t col, void* const* dst, uint64_t n_dst);
@@ -193,7 +200,7 @@ struct StrView {
     const char* p;
     uint32_t    len;
 };
-void varchar_index(const uint8_t* pages, uint64_t n_pages, uint64_t num_rows,
+void varchar_index(const uint8_t* const* pages, uint64_t n_pages, uint64_t num_rows,
                    std::vector<StrView>& rows, std::vector<std::string>& stitch);
 // Gather rows[idx[i]] and encode them as VARCHAR pages (reference fill rule
 // src/build_table.cpp:595-677).

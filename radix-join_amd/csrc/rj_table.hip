@@ -80,7 +80,8 @@ Table* table_adopt(Context* ctx, uint64_t num_rows, uint64_t n_cols, const int32
     return t.release();
 }
 
-Table* table_upload(Context* ctx, const rj_input* in) {
+Table* table_upload(Context* ctx, const rj_input* in, const std::vector<bool>* col_used,
+                    bool borrow_varchar) {
     if (!in) throw_fmt(RJ_ERR_ARG, "null input");
     if (in->num_rows > 0xfffffff0ull)
         throw_fmt(RJ_ERR_UNSUPPORTED, "more than 2^32 rows in one table");
@@ -101,13 +102,27 @@ Table* table_upload(Context* ctx, const rj_input* in) {
             c.type = hc.type;
             c.n_pages = hc.n_pages;
             if (c.type < RJ_INT32 || c.type > RJ_VARCHAR) throw_fmt(RJ_ERR_ARG, "bad column type");
+            if (col_used && !(*col_used)[ci]) {  // no ScanNode outputs this column
+                c.skipped = true;
+                c.n_pages = 0;
+                continue;
+            }
             if (c.type == RJ_VARCHAR) {
-                c.host_pages.resize(hc.n_pages * PAGE_BYTES);
                 const void* const* pages = hc.pages;
-                uint8_t*           dst = c.host_pages.data();
-                parallel_for(hc.n_pages, 256, [&](size_t b, size_t e) {
-                    for (size_t p = b; p < e; ++p) memcpy(dst + p * PAGE_BYTES, pages[p], PAGE_BYTES);
-                });
+                c.vc_pages.resize(hc.n_pages);
+                if (borrow_varchar) {
+                    for (uint64_t p = 0; p < hc.n_pages; ++p)
+                        c.vc_pages[p] = static_cast<const uint8_t*>(pages[p]);
+                } else {
+                    c.host_pages.resize(hc.n_pages * PAGE_BYTES);
+                    uint8_t* dst = c.host_pages.data();
+                    parallel_for(hc.n_pages, 256, [&](size_t b, size_t e) {
+                        for (size_t p = b; p < e; ++p) {
+                            memcpy(dst + p * PAGE_BYTES, pages[p], PAGE_BYTES);
+                            c.vc_pages[p] = dst + p * PAGE_BYTES;
+                        }
+                    });
+                }
                 continue;
             }
             if (hc.n_pages == 0) continue;
@@ -130,7 +145,7 @@ Table* table_upload(Context* ctx, const rj_input* in) {
         }
         ctx->sync();
         for (TableColumn& c : t->cols)
-            if (c.type != RJ_VARCHAR) analyse_column(ctx, c, t->num_rows);
+            if (c.type != RJ_VARCHAR && !c.skipped) analyse_column(ctx, c, t->num_rows);
     } catch (...) {
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipEventDestroy(ev[0]);

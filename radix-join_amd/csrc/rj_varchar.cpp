@@ -22,19 +22,19 @@ static inline uint16_t rd16(const uint8_t* p) {
     return v;
 }
 
-void varchar_index(const uint8_t* pages, uint64_t n_pages, uint64_t num_rows,
+void varchar_index(const uint8_t* const* pages, uint64_t n_pages, uint64_t num_rows,
                    std::vector<StrView>& rows, std::vector<std::string>& stitch) {
     rows.assign(num_rows, StrView{nullptr, 0});
     // long strings are stitched into owned std::strings; reserve so pointers stay valid
     uint64_t n_long = 0;
     for (uint64_t p = 0; p < n_pages; ++p)
-        if (rd16(pages + p * PAGE_BYTES) == 0xffff) ++n_long;
+        if (rd16(pages[p]) == 0xffff) ++n_long;
     stitch.clear();
     stitch.reserve(n_long);
     uint64_t row = 0;
     int64_t  last_long = -1;  // index into stitch of the row being continued
     for (uint64_t p = 0; p < n_pages; ++p) {
-        const uint8_t* page = pages + p * PAGE_BYTES;
+        const uint8_t* page = pages[p];
         uint16_t       nr = rd16(page);
         if (nr == 0xffff) {
             uint16_t nchars = rd16(page + 2);
@@ -77,7 +77,7 @@ void varchar_index(const uint8_t* pages, uint64_t n_pages, uint64_t num_rows,
         uint64_t r = 0;
         size_t   li = 0;
         for (uint64_t p = 0; p < n_pages; ++p) {
-            uint16_t nr = rd16(pages + p * PAGE_BYTES);
+            uint16_t nr = rd16(pages[p]);
             if (nr == 0xffff) {
                 rows[r] = StrView{stitch[li].data(), (uint32_t)stitch[li].size()};
                 ++li;

@@ -76,8 +76,10 @@ def _aliases(tree):
     return {tree["alias"]} if "scan" in tree else _aliases(tree["left"]) | _aliases(tree["right"])
 
 
-def build_plan(query, schema, tables) -> pl.Plan:
-    """The Plan the harness would hand to Contest::execute for this query."""
+def build_plan(query, schema, tables, by_alias: bool = False) -> pl.Plan:
+    """The Plan the harness would hand to Contest::execute for this query.  `tables` maps base
+    table name -> ColumnarTable (or alias -> ColumnarTable with by_alias=True: one separately
+    filtered input per scan, as the harness produces)."""
     plan = pl.Plan()
     col_index = {t: {c[0]: i for i, c in enumerate(cols)} for t, cols in schema.items()}
     col_type = {t: {c[0]: pl.TYPE_IDS[c[1]] for c in cols} for t, cols in schema.items()}
@@ -100,7 +102,7 @@ def build_plan(query, schema, tables) -> pl.Plan:
         (read_sql.cpp:1008-1009,1056-1062)."""
         if "scan" in tree:
             table = tree["scan"]
-            inp = plan.new_input(tables[table])
+            inp = plan.new_input(tables[tree["alias"]] if by_alias else tables[table])
             outs = [(col_index[table][c], typ((a, c))) for a, c in required]
             return plan.new_scan_node(inp, outs), list(required)
         la = _aliases(tree["left"])

@@ -208,6 +208,50 @@ def pack_varchar(strings) -> np.ndarray:
     return np.stack(pages)
 
 
+def pack_varchar_fixed(codes, digits: int = 10, prefix: bytes = b"") -> np.ndarray:
+    """Vectorised VARCHAR packer for large synthetic columns: row i is `prefix` + the
+    zero-padded decimal `codes[i]` (all strings the same length, no NULLs), packed with the
+    reference's fill rule (plan.h:301-320), which for equal lengths gives a constant number
+    of rows per page."""
+    codes = np.asarray(codes).astype(np.uint64)
+    n = codes.shape[0]
+    L = len(prefix) + digits
+    if n == 0:
+        return np.zeros((0, PAGE_SIZE), dtype=np.uint8)
+    ch = np.empty((n, L), dtype=np.uint8)
+    if prefix:
+        ch[:, : len(prefix)] = np.frombuffer(prefix, dtype=np.uint8)
+    c = codes.copy()
+    for d in range(digits - 1, -1, -1):
+        ch[:, len(prefix) + d] = (48 + (c % 10)).astype(np.uint8)
+        c //= 10
+    R = 0  # rows per full page: row k (0-based) fits iff 4 + 2(k+1) + (k+1)L + k//8 + 1 <= 8192
+    while 4 + 2 * (R + 1) + (R + 1) * L + (R // 8 + 1) <= PAGE_SIZE:
+        R += 1
+    npages = (n + R - 1) // R
+    pages = np.zeros((npages, PAGE_SIZE), dtype=np.uint8)
+    full = n // R
+
+    def fill(dst, r, chars):  # dst [k, 8192] pages each holding exactly r rows
+        hv = dst[:, :4].view(np.uint16)
+        hv[:, 0] = r
+        hv[:, 1] = r
+        dst[:, 4 : 4 + 2 * r] = ((np.arange(1, r + 1, dtype=np.uint16)) * L).astype(np.uint16).view(np.uint8)
+        dst[:, 4 + 2 * r : 4 + 2 * r + r * L] = chars
+        nb = (r + 7) // 8
+        bm = np.full(nb, 0xFF, dtype=np.uint8)
+        if r % 8:
+            bm[-1] = (1 << (r % 8)) - 1
+        dst[:, PAGE_SIZE - nb :] = bm
+
+    if full:
+        fill(pages[:full], R, ch[: full * R].reshape(full, R * L))
+    rem = n - full * R
+    if rem:
+        fill(pages[full : full + 1], rem, ch[full * R :].reshape(1, rem * L))
+    return pages
+
+
 def unpack_varchar(pages: np.ndarray, num_rows: int) -> list:
     """Decode VARCHAR pages -> list of ``bytes | None`` of length num_rows."""
     out: list = [None] * num_rows

@@ -49,7 +49,10 @@ def tree(node):
     node = strip(node)
     nt = node["Node Type"]
     if nt in ("Seq Scan", "Index Only Scan", "Index Scan", "Bitmap Heap Scan"):
-        return {"scan": node["Relation Name"], "alias": node["Alias"]}
+        # "Plan Rows" = PostgreSQL's estimate of the scan's output after its filter, per parallel
+        # worker: sizes the synthetic input of this scan in scripts/job_bench.py
+        return {"scan": node["Relation Name"], "alias": node["Alias"], "rows": int(node.get("Plan Rows", 0)),
+                "filtered": "Filter" in node or "Index Cond" in node}
     if nt != "Hash Join":
         raise ValueError(nt)
     assert node.get("Join Type", "Inner") == "Inner"
