@@ -60,14 +60,15 @@ struct Words {
 // digit's run contiguously (software write-combining), see rj_kernels.hip.
 // Geometry is overridable at build time (-DRJ_PT_THREADS=...) for tuning runs.
 #ifndef RJ_PT_THREADS
-#define RJ_PT_THREADS 512
+#define RJ_PT_THREADS 1024
 #endif
 #ifndef RJ_PT_ITEMS
 #define RJ_PT_ITEMS 16
 #endif
 constexpr int PT_THREADS = RJ_PT_THREADS;         // waves = PT_THREADS / 64
 constexpr int PT_ITEMS   = RJ_PT_ITEMS;           // tuples per thread per tile
-constexpr int PT_TILE    = PT_THREADS * PT_ITEMS; // 8192 tuples = 32 KiB per word array
+constexpr int PT_TILE    = PT_THREADS * PT_ITEMS; // 16384 tuples = 64 KiB of LDS staging; longer
+                                                  // digit runs per tile = fewer partial HBM lines
 constexpr int PT_MAXF    = 512;                   // max fan-out per pass (9 bits)
 constexpr int PT_MAXBITS = 9;
 static_assert(PT_THREADS >= PT_MAXF, "thread d scans digit d");
