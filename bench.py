@@ -212,7 +212,8 @@ def main():
             dist.init_process_group(backend)
 
     n = args.rows
-    ctx = capi.Context(device=dev_index, profile=True)
+    # RJ_BENCH_PROFILE=0 drops the per-kernel HIP events (diagnostic: what the bracketing costs)
+    ctx = capi.Context(device=dev_index, profile=os.environ.get("RJ_BENCH_PROFILE", "1") != "0")
     rk, rp, sk, sp = make_relations(n, rank, world, device)
     R = adopt(ctx, [rk, rp])
     S = adopt(ctx, [sk, sp])
@@ -292,7 +293,7 @@ def main():
                 "device": info["name"],
                 "arch": info["arch"],
             },
-            "roofline": roofline(stats, n, n, args.steps),
+            "roofline": roofline(stats, n, n, args.steps) if stats else None,
         }
         if not distributed and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample)

@@ -1,5 +1,7 @@
 // rj_api.hip — the extern "C" boundary (include/rj.h).  Every entry point turns
 // C++ exceptions into status codes + rj_last_error().
+#include <chrono>
+#include <cstdlib>
 #include <mutex>
 
 #include "rj_internal.hpp"
@@ -153,6 +155,9 @@ int rj_execute(rj_context* ctx, const rj_plan* plan, rj_result** out) {
                 col_used[nd.base_table_id][nd.out_idx[k]] = true;
             }
         }
+        const char* dg = getenv("RJ_DIAG");
+        const bool  diag = dg && atoi(dg) >= 2;
+        auto        t0 = std::chrono::steady_clock::now();
         std::vector<std::unique_ptr<Table>> owned(plan->n_inputs);
         std::vector<Table*>                 ts(plan->n_inputs, nullptr);
         rj_input                            none{};
@@ -161,7 +166,14 @@ int rj_execute(rj_context* ctx, const rj_plan* plan, rj_result** out) {
                                         used[i] ? &col_used[i] : nullptr, /*borrow_varchar=*/true));
             ts[i] = owned[i].get();
         }
+        auto t1 = std::chrono::steady_clock::now();
         *out = static_cast<rj_result*>(execute_plan(ctx, plan, ts.data(), plan->n_inputs, 0));
+        if (diag) {
+            auto   t2 = std::chrono::steady_clock::now();
+            double up = std::chrono::duration<double, std::milli>(t1 - t0).count();
+            double ex = std::chrono::duration<double, std::milli>(t2 - t1).count();
+            fprintf(stderr, "[rj host] upload %.2f ms, plan (device + host VARCHAR) %.2f ms\n", up, ex);
+        }
     });
 }
 

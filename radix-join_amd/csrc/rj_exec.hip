@@ -11,6 +11,7 @@
 //     row index into the child, gathered per output column.
 //   * At the root the streams are written straight into Page images.
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <set>
 
@@ -156,7 +157,7 @@ class Exec {
     int            flags;
     Launch         L;
     std::map<std::pair<const Table*, int>, DCol> decoded_;
-    std::map<std::pair<int, int>, std::pair<std::vector<StrView>, std::vector<std::string>>> vc_index_;
+    std::map<std::pair<int, int>, std::vector<uint64_t>> vc_dir_;  // VARCHAR page directories
 
     // ------------------------------------------------------------- scan side
     DCol table_col(const Table* t, int c) {
@@ -698,18 +699,27 @@ class Exec {
             throw_fmt(RJ_ERR_ARG, "VARCHAR column without provenance");
         const Table*       t = tables[src.vc_table];
         const TableColumn& tc = t->cols[src.vc_col];
+        const bool diag = tune("RJ_DIAG", 0) >= 2;
+        auto       tv0 = std::chrono::steady_clock::now();
         std::vector<uint32_t> ids(n);
         RJ_HIP(hipMemcpyAsync(ids.data(), dev_rowids, n * 4, hipMemcpyDeviceToHost, ctx->stream));
         ctx->sync();
-        auto  key = std::make_pair(src.vc_table, src.vc_col);
-        auto  it = vc_index_.find(key);
-        if (it == vc_index_.end()) {
-            it = vc_index_.emplace(key, std::make_pair(std::vector<StrView>(), std::vector<std::string>()))
-                     .first;
-            varchar_index(tc.vc_pages.data(), tc.vc_pages.size(), t->num_rows,
-                          it->second.first, it->second.second);
+        auto tv1 = std::chrono::steady_clock::now();
+        auto key = std::make_pair(src.vc_table, src.vc_col);
+        auto it = vc_dir_.find(key);
+        if (it == vc_dir_.end()) {
+            it = vc_dir_.emplace(key, std::vector<uint64_t>()).first;
+            varchar_dir_build(tc.vc_pages.data(), tc.vc_pages.size(), t->num_rows, it->second);
         }
-        varchar_gather_encode(it->second.first, ids.data(), n, rc.host_pages, rc.n_pages);
+        auto tv2 = std::chrono::steady_clock::now();
+        varchar_gather_encode(tc.vc_pages.data(), tc.vc_pages.size(), it->second, ids.data(), n,
+                              rc.host_pages, rc.n_pages);
+        if (diag) {
+            auto tv3 = std::chrono::steady_clock::now();
+            auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            fprintf(stderr, "[rj host]   varchar col: %llu rows, wait+D2H %.2f ms, page directory %.2f ms, gather+encode %.2f ms\n",
+                    (unsigned long long)n, ms(tv0, tv1), ms(tv1, tv2), ms(tv2, tv3));
+        }
     }
 };
 

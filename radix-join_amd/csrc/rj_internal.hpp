@@ -194,18 +194,15 @@ Table* table_adopt(Context* ctx, uint64_t num_rows, uint64_t n_cols, const int32
 void   result_copy_pages(Result* r, uint64_t col, void* const* dst, uint64_t n_dst);
 
 // rj_varchar.cpp (host only)
-// Decode a VARCHAR column's pages into (pointer,length) views, one per row; NULL rows get
-// ptr == nullptr.  `stitch` owns long strings that span pages.
-struct StrView {
-    const char* p;
-    uint32_t    len;
-};
-void varchar_index(const uint8_t* const* pages, uint64_t n_pages, uint64_t num_rows,
-                   std::vector<StrView>& rows, std::vector<std::string>& stitch);
-// Gather rows[idx[i]] and encode them as VARCHAR pages (reference fill rule
+// Page directory of a VARCHAR column: row_base[p] = rows before page p, row_base[n_pages] =
+// rows the pages hold.  Throws "row_idx" if they hold more than num_rows.
+void varchar_dir_build(const uint8_t* const* pages, uint64_t n_pages, uint64_t num_rows,
+                       std::vector<uint64_t>& row_base);
+// Gather the strings of rows idx[0..n) and encode them as VARCHAR pages (reference fill rule
 // src/build_table.cpp:595-677).
-void varchar_gather_encode(const std::vector<StrView>& rows, const uint32_t* idx, uint64_t n,
-                           std::vector<uint8_t>& out_pages, uint64_t& n_pages);
+void varchar_gather_encode(const uint8_t* const* pages, uint64_t n_pages,
+                           const std::vector<uint64_t>& row_base, const uint32_t* idx, uint64_t n,
+                           std::vector<uint8_t>& out_pages, uint64_t& n_out_pages);
 
 }  // namespace rj
 

@@ -3,11 +3,16 @@
 // VARCHAR is never a join key in the workload (reference ANNOUNCEMENTS.md:11), so
 // strings never travel to the GPU: a VARCHAR column moves through the plan as a
 // row-id column of its base table and is resolved here, at the root.
-//   varchar_index          — one pass over the pages, restating the VARCHAR branch of
-//                            Table::from_columnar (reference src/build_table.cpp:382-428)
-//   varchar_gather_encode  — rows -> pages with the fill rule of Table::to_columnar
-//                            (reference src/build_table.cpp:595-677) / ColumnInserter<string>
-//                            (reference include/plan.h:301-334)
+//   varchar_dir_build      — a page directory (rows before each page): 4 bytes read per
+//                            page, instead of decoding every row the way the VARCHAR branch
+//                            of Table::from_columnar does (reference
+//                            src/build_table.cpp:382-428)
+//   varchar_gather_encode  — row ids -> strings (page lookup + bitmap popcount + offset
+//                            array, the layout of build_table.cpp:406-427 / long-string
+//                            pages :384-405) -> pages with the fill rule of
+//                            Table::to_columnar (reference src/build_table.cpp:595-677) /
+//                            ColumnInserter<string> (reference include/plan.h:301-334),
+//                            in parallel slabs.
 #include <algorithm>
 #include <cstring>
 #include <thread>
@@ -22,74 +27,77 @@ static inline uint16_t rd16(const uint8_t* p) {
     return v;
 }
 
-void varchar_index(const uint8_t* const* pages, uint64_t n_pages, uint64_t num_rows,
-                   std::vector<StrView>& rows, std::vector<std::string>& stitch) {
-    rows.assign(num_rows, StrView{nullptr, 0});
-    // long strings are stitched into owned std::strings; reserve so pointers stay valid
-    uint64_t n_long = 0;
-    for (uint64_t p = 0; p < n_pages; ++p)
-        if (rd16(pages[p]) == 0xffff) ++n_long;
-    stitch.clear();
-    stitch.reserve(n_long);
-    uint64_t row = 0;
-    int64_t  last_long = -1;  // index into stitch of the row being continued
+void varchar_dir_build(const uint8_t* const* pages, uint64_t n_pages, uint64_t num_rows,
+                       std::vector<uint64_t>& row_base) {
+    row_base.assign(n_pages + 1, 0);
+    uint64_t rows = 0;
     for (uint64_t p = 0; p < n_pages; ++p) {
-        const uint8_t* page = pages[p];
-        uint16_t       nr = rd16(page);
-        if (nr == 0xffff) {
-            uint16_t nchars = rd16(page + 2);
-            if (row >= num_rows) throw_fmt(RJ_ERR_DATA, "row_idx");
-            stitch.emplace_back(reinterpret_cast<const char*>(page + 4), nchars);
-            last_long = (int64_t)stitch.size() - 1;
-            rows[row] = StrView{stitch.back().data(), (uint32_t)stitch.back().size()};
-            ++row;
-        } else if (nr == 0xfffe) {
-            uint16_t nchars = rd16(page + 2);
-            if (row == 0 || last_long < 0)
+        row_base[p] = rows;
+        uint16_t nr = rd16(pages[p]);
+        if (nr == 0xffff)
+            rows += 1;  // first page of a long string: one row (build_table.cpp:384-391)
+        else if (nr == 0xfffe) {
+            if (p == 0 || rows == 0)
                 throw_fmt(RJ_ERR_DATA, "long string page 0xfffe must follows a string");
-            std::string& s = stitch[(size_t)last_long];
-            s.append(reinterpret_cast<const char*>(page + 4), nchars);
-            rows[row - 1] = StrView{s.data(), (uint32_t)s.size()};
-        } else {
-            last_long = -1;
-            uint16_t       nnn = rd16(page + 2);
-            const uint8_t* offs = page + 4;
-            const char*    data = reinterpret_cast<const char*>(page) + 4 + (size_t)nnn * 2;
-            const uint8_t* bitmap = page + PAGE_BYTES - (nr + 7) / 8;
-            uint32_t       di = 0, prev = 0;
-            for (uint32_t i = 0; i < nr; ++i) {
-                if (row >= num_rows) throw_fmt(RJ_ERR_DATA, "row_idx");
-                if ((bitmap[i >> 3] >> (i & 7)) & 1) {
-                    uint32_t end = rd16(offs + (size_t)di * 2);
-                    rows[row] = StrView{data + prev, end - prev};
-                    prev = end;
-                    ++di;
-                }
-                ++row;
-            }
-        }
+        } else
+            rows += nr;
     }
-    // a stitched string may have been re-allocated by append(): refresh the views
-    // (append can move the buffer; rows[] of earlier long strings stay valid because
-    // every std::string owns its own buffer, but the LAST append per string is what
-    // counts — recompute all long-string views once)
-    {
-        uint64_t r = 0;
-        size_t   li = 0;
-        for (uint64_t p = 0; p < n_pages; ++p) {
-            uint16_t nr = rd16(pages[p]);
-            if (nr == 0xffff) {
-                rows[r] = StrView{stitch[li].data(), (uint32_t)stitch[li].size()};
-                ++li;
-                ++r;
-            } else if (nr != 0xfffe) {
-                r += nr;
-            }
-        }
-    }
+    row_base[n_pages] = rows;
+    // more rows in the pages than the table declares: reference throws "row_idx" (:388,:419)
+    if (rows > num_rows) throw_fmt(RJ_ERR_DATA, "row_idx");
 }
 
 namespace {
+
+// bits set in bitmap[0, i)
+inline uint32_t popcount_below(const uint8_t* bitmap, uint32_t i) {
+    uint32_t c = 0, w = 0;
+    for (; w + 64 <= i; w += 64) {
+        uint64_t x;
+        memcpy(&x, bitmap + w / 8, 8);
+        c += (uint32_t)__builtin_popcountll(x);
+    }
+    for (; w + 8 <= i; w += 8) c += (uint32_t)__builtin_popcount(bitmap[w / 8]);
+    if (w < i) c += (uint32_t)__builtin_popcount(bitmap[w / 8] & ((1u << (i - w)) - 1u));
+    return c;
+}
+
+struct Lookup {
+    const uint8_t* const*        pages;
+    uint64_t                     n_pages;
+    const std::vector<uint64_t>& row_base;
+    std::string                  scratch;  // long strings are stitched here
+
+    // -> false for NULL; otherwise [*p, *p + *len) holds the string until the next call
+    bool get(uint64_t row, const char** p, uint32_t* len) {
+        if (row >= row_base[n_pages]) return false;  // rows the pages do not cover are NULL
+        uint64_t pg = (uint64_t)(std::upper_bound(row_base.begin(), row_base.end(), row) -
+                                 row_base.begin()) - 1;
+        const uint8_t* page = pages[pg];
+        uint16_t       nr = rd16(page);
+        if (nr == 0xffff) {
+            scratch.assign(reinterpret_cast<const char*>(page + 4), rd16(page + 2));
+            for (uint64_t q = pg + 1; q < n_pages && rd16(pages[q]) == 0xfffe; ++q)
+                scratch.append(reinterpret_cast<const char*>(pages[q] + 4), rd16(pages[q] + 2));
+            *p = scratch.data();
+            *len = (uint32_t)scratch.size();
+            return true;
+        }
+        uint32_t       i = (uint32_t)(row - row_base[pg]);
+        const uint8_t* bitmap = page + PAGE_BYTES - (nr + 7) / 8;
+        if (!((bitmap[i >> 3] >> (i & 7)) & 1)) return false;
+        uint32_t       idx = popcount_below(bitmap, i);
+        uint16_t       nnn = rd16(page + 2);
+        const uint8_t* offs = page + 4;
+        const char*    data = reinterpret_cast<const char*>(page) + 4 + (size_t)nnn * 2;
+        uint32_t       end = rd16(offs + (size_t)idx * 2);
+        uint32_t       beg = idx ? rd16(offs + (size_t)(idx - 1) * 2) : 0;
+        *p = data + beg;
+        *len = end - beg;
+        return true;
+    }
+};
+
 struct PageWriter {
     std::vector<uint8_t>& out;
     uint64_t&             n_pages;
@@ -135,22 +143,21 @@ struct PageWriter {
             off += chunk;
         }
     }
-    void add(const StrView& v) {
-        if (v.p == nullptr) {  // NULL
-            if (4 + offs.size() * 2 + chars.size() + (num_rows / 8 + 1) > PAGE_BYTES) save_page();
-            bit(num_rows, false);
-            ++num_rows;
-            return;
-        }
-        if (v.len > PAGE_BYTES - 7) {
+    void add_null() {
+        if (4 + offs.size() * 2 + chars.size() + (num_rows / 8 + 1) > PAGE_BYTES) save_page();
+        bit(num_rows, false);
+        ++num_rows;
+    }
+    void add(const char* p, uint32_t len) {
+        if (len > PAGE_BYTES - 7) {
             if (num_rows > 0) save_page();
-            save_long(v.p, v.len);
+            save_long(p, len);
             return;
         }
-        if (4 + (offs.size() + 1) * 2 + (chars.size() + v.len) + (num_rows / 8 + 1) > PAGE_BYTES)
+        if (4 + (offs.size() + 1) * 2 + (chars.size() + len) + (num_rows / 8 + 1) > PAGE_BYTES)
             save_page();
         bit(num_rows, true);
-        chars.insert(chars.end(), v.p, v.p + v.len);
+        chars.insert(chars.end(), p, p + len);
         offs.push_back((uint16_t)chars.size());
         ++num_rows;
     }
@@ -160,45 +167,59 @@ struct PageWriter {
 };
 }  // namespace
 
-void varchar_gather_encode(const std::vector<StrView>& rows, const uint32_t* idx, uint64_t n,
-                           std::vector<uint8_t>& out_pages, uint64_t& n_pages) {
-    // Pages are independent once their first row is known, but that depends on the
-    // greedy fill; encode in parallel slabs (each slab starts a fresh page — a valid,
-    // slightly less dense layout) when the output is large.
-    const uint64_t SLAB = 1u << 20;
+void varchar_gather_encode(const uint8_t* const* pages, uint64_t n_pages,
+                           const std::vector<uint64_t>& row_base, const uint32_t* idx, uint64_t n,
+                           std::vector<uint8_t>& out_pages, uint64_t& n_out_pages) {
+    // Slabs of 64 K rows are encoded independently (each starts a fresh page — a valid,
+    // marginally less dense layout than one greedy pass) so large outputs use all host cores.
+    const uint64_t SLAB = 1u << 16;
     unsigned       hw = std::thread::hardware_concurrency();
     uint64_t       n_slabs = (n + SLAB - 1) / SLAB;
     out_pages.clear();
-    n_pages = 0;
-    static const StrView null_view{nullptr, 0};
+    n_out_pages = 0;
     auto encode = [&](uint64_t b, uint64_t e, std::vector<uint8_t>& out, uint64_t& np) {
+        Lookup     lk{pages, n_pages, row_base, {}};
         PageWriter w{out, np};
+        out.reserve((e - b) * 24 + PAGE_BYTES);
         for (uint64_t i = b; i < e; ++i) {
-            uint32_t r = idx[i];
-            w.add(r < rows.size() ? rows[r] : null_view);
+            const char* p;
+            uint32_t    len;
+            if (lk.get(idx[i], &p, &len))
+                w.add(p, len);
+            else
+                w.add_null();
         }
         w.finish();
     };
     if (n_slabs <= 1 || hw <= 1) {
-        encode(0, n, out_pages, n_pages);
+        encode(0, n, out_pages, n_out_pages);
         return;
     }
     std::vector<std::vector<uint8_t>> parts(n_slabs);
     std::vector<uint64_t>             counts(n_slabs, 0);
-    unsigned                          nt = std::min<uint64_t>(std::min<unsigned>(hw, 16), n_slabs);
+    unsigned                          nt = (unsigned)std::min<uint64_t>(std::min<unsigned>(hw, 32), n_slabs);
     std::vector<std::thread>          th;
+    std::vector<std::string>          errs(nt);
     for (unsigned t = 0; t < nt; ++t)
         th.emplace_back([&, t] {
-            for (uint64_t s = t; s < n_slabs; s += nt)
-                encode(s * SLAB, std::min(n, (s + 1) * SLAB), parts[s], counts[s]);
+            try {
+                for (uint64_t s = t; s < n_slabs; s += nt)
+                    encode(s * SLAB, std::min(n, (s + 1) * SLAB), parts[s], counts[s]);
+            } catch (const std::exception& e) {
+                errs[t] = e.what();
+            }
         });
     for (auto& x : th) x.join();
+    for (auto& e : errs)
+        if (!e.empty()) throw_fmt(RJ_ERR_NOMEM, "VARCHAR encode: %s", e.c_str());
     size_t total = 0;
     for (auto& p : parts) total += p.size();
-    out_pages.reserve(total);
+    out_pages.resize(total);
+    size_t off = 0;
     for (uint64_t s = 0; s < n_slabs; ++s) {
-        out_pages.insert(out_pages.end(), parts[s].begin(), parts[s].end());
-        n_pages += counts[s];
+        memcpy(out_pages.data() + off, parts[s].data(), parts[s].size());
+        off += parts[s].size();
+        n_out_pages += counts[s];
     }
 }
 
