@@ -74,6 +74,56 @@ def pack_pages_gpu(values: torch.Tensor) -> torch.Tensor:
     return pages.view(torch.uint8).view(npages, 8192)
 
 
+ROWS64 = 1007
+
+
+def pack_pages_gpu64(values: torch.Tensor) -> torch.Tensor:
+    """INT64 values (device) -> Page images, 1007 rows per full page, values from byte 8
+    (layout: reference src/build_table.cpp:515-524)."""
+    n = values.numel()
+    npages = (n + ROWS64 - 1) // ROWS64
+    pages = torch.zeros((npages, 1024), dtype=torch.int64, device=values.device)
+    full = n // ROWS64
+    if full:
+        pages[:full, 1 : 1 + ROWS64] = values[: full * ROWS64].view(full, ROWS64)
+    rem = n - full * ROWS64
+    if rem:
+        pages[full, 1 : 1 + rem] = values[full * ROWS64 :]
+    b = pages.view(torch.uint8).view(npages, 8192)
+    cnt = torch.full((npages,), ROWS64, dtype=torch.int32, device=values.device)
+    if rem:
+        cnt[-1] = rem
+    hdr = (cnt | (cnt << 16)).view(torch.uint8).view(npages, 4)
+    b[:, :4] = hdr
+    nbf = (ROWS64 + 7) // 8  # 126 bitmap bytes of a full page, last byte has 7 valid bits
+    if full:
+        b[:full, 8192 - nbf :] = 255
+        b[:full, 8191] = (1 << (ROWS64 % 8)) - 1
+    if rem:
+        nb = (rem + 7) // 8
+        b[full, 8192 - nb :] = 255
+        if rem % 8:
+            b[full, 8191] = (1 << (rem % 8)) - 1
+    return b
+
+
+def zipf_keys(n_keys, n, s, device, gen):
+    """n draws of a Zipf(s) rank over [0, n_keys), scattered through a fixed bijection so that hot
+    keys are not numerically adjacent (skew on the probe side only)."""
+    w = torch.arange(1, n_keys + 1, device=device, dtype=torch.float64).pow_(-s)
+    cdf = torch.cumsum(w, 0)
+    del w
+    cdf /= cdf[-1].clone()
+    out = torch.empty(n, device=device, dtype=torch.int64)
+    step = 1 << 27
+    for i in range(0, n, step):
+        m = min(step, n - i)
+        u = torch.rand(m, device=device, dtype=torch.float64, generator=gen)
+        out[i : i + m] = torch.searchsorted(cdf, u, right=True).clamp_(max=n_keys - 1)
+    del cdf
+    return ((out * 7919 + 13) % n_keys).to(torch.int32)
+
+
 def make_relations(n, rank, world, device):
     """R: unique keys (a permutation of [0, world*n)), payload = global row index.
     S: uniform iid keys over R's domain, payload = global row index."""
@@ -93,17 +143,19 @@ def make_relations(n, rank, world, device):
 
 
 def adopt(ctx, cols):
-    pages = [pack_pages_gpu(c) for c in cols]
+    pages = [pack_pages_gpu64(c) if c.dtype == torch.int64 else pack_pages_gpu(c) for c in cols]
+    types = [pl.INT64 if c.dtype == torch.int64 else pl.INT32 for c in cols]
     torch.cuda.synchronize()
     n = cols[0].numel()
-    return ctx.adopt_device(n, [pl.INT32] * len(cols), [p.data_ptr() for p in pages], [p.shape[0] for p in pages], keep=pages)
+    return ctx.adopt_device(n, types, [p.data_ptr() for p in pages], [p.shape[0] for p in pages], keep=pages)
 
 
-def join_plan():
+def join_plan(payload=None):
+    payload = pl.INT32 if payload is None else payload
     p = pl.Plan()
-    p.new_scan_node(0, [(0, pl.INT32), (1, pl.INT32)])
-    p.new_scan_node(1, [(0, pl.INT32), (1, pl.INT32)])
-    p.new_join_node(True, 0, 1, 0, 0, [(0, pl.INT32), (1, pl.INT32), (3, pl.INT32)])
+    p.new_scan_node(0, [(0, pl.INT32), (1, payload)])
+    p.new_scan_node(1, [(0, pl.INT32), (1, payload)])
+    p.new_join_node(True, 0, 1, 0, 0, [(0, pl.INT32), (1, payload), (3, payload)])
     p.root = 2
     return p
 
@@ -136,10 +188,14 @@ def cpu_baseline(sample_rows):
     }
 
 
-def roofline(stats, rows_build, rows_probe, steps_profiled):
+def roofline(stats, rows_build, rows_probe, steps_profiled, payload_bytes=4):
+    # SURVEY.md §8d with p = payload bytes: scatter 2(k+p), probe (k+p)+(k+p)+(k+2p)
+    algo_bytes = dict(ALGO_BYTES)
+    algo_bytes["pass1_scatter"] = algo_bytes["pass2_scatter"] = 2.0 * (4 + payload_bytes)
+    algo_bytes["join_build_probe"] = 3.0 * 4 + 4.0 * payload_bytes
     per = {}
     for s in stats:
-        if s["name"] in ALGO_BYTES and s["launches"]:
+        if s["name"] in algo_bytes and s["launches"]:
             per[s["name"]] = s
     if not per:
         return None
@@ -151,7 +207,7 @@ def roofline(stats, rows_build, rows_probe, steps_profiled):
     else:
         # partition kernels run once per relation per step with equal cardinalities here
         tuples = (rows_build + rows_probe) / 2.0
-    algo = ALGO_BYTES[name] * tuples
+    algo = algo_bytes[name] * tuples
     achieved = algo / (avg_ms * 1e-3) / 1e9
     # HBM bytes per launch from the PMC passes committed under profiles/ (bench.py cannot
     # collect hardware counters itself); only valid for the size they were collected at
@@ -159,7 +215,7 @@ def roofline(stats, rows_build, rows_probe, steps_profiled):
     try:
         with open(os.path.join(ROOT, "profiles", "traffic_r01.json")) as f:
             t = json.load(f)
-        if t["rows_per_relation"] == rows_probe == rows_build:
+        if t["rows_per_relation"] == rows_probe == rows_build and payload_bytes == 4:
             traffic = t["bytes_per_launch"].get(name)
     except Exception:
         traffic = None
@@ -186,6 +242,8 @@ def main():
     ap.add_argument("--rows", type=int, default=100_000_000, help="rows per relation per GPU")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--zipf", type=float, default=0.0, help="Zipf exponent of the probe keys (config 3: 0.9); N=1 only")
+    ap.add_argument("--payload64", action="store_true", help="INT64 payload columns (config 3); N=1 only")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -215,13 +273,21 @@ def main():
     # RJ_BENCH_PROFILE=0 drops the per-kernel HIP events (diagnostic: what the bracketing costs)
     ctx = capi.Context(device=dev_index, profile=os.environ.get("RJ_BENCH_PROFILE", "1") != "0")
     rk, rp, sk, sp = make_relations(n, rank, world, device)
+    if (args.zipf or args.payload64) and distributed:
+        raise SystemExit("--zipf / --payload64 are single-GPU workloads")
+    if args.zipf:
+        g = torch.Generator(device=device)
+        g.manual_seed(3)
+        sk = zipf_keys(n, n, args.zipf, device, g)
+    if args.payload64:
+        rp, sp = rp.to(torch.int64) * 1_000_003, sp.to(torch.int64) * 1_000_003
     R = adopt(ctx, [rk, rp])
     S = adopt(ctx, [sk, sp])
     del rk, rp, sk, sp
     torch.cuda.empty_cache()
 
     if not distributed:
-        plan = join_plan()
+        plan = join_plan(pl.INT64 if args.payload64 else pl.INT32)
 
         def step():
             res = ctx.execute_resident(plan, [R, S])
@@ -286,14 +352,15 @@ def main():
             "dtype": "int32",
             "data": "synthetic",
             "config": {
-                "workload": f"single JoinNode, {n} x {n} INT32 uniform keys per GPU (build = permutation, probe = iid), "
-                "1 INT32 payload col per side, Page-packed inputs resident in HBM, Page-encoded output in HBM",
+                "workload": f"single JoinNode, {n} x {n} INT32 keys per GPU (build = permutation, probe = "
+                + (f"Zipf-{args.zipf}" if args.zipf else "uniform iid") + "), 1 "
+                + ("INT64" if args.payload64 else "INT32") + " payload col per side, Page-packed inputs resident in HBM, Page-encoded output in HBM",
                 "rows_per_relation_per_gpu": n,
                 "parallelism": "single GPU" if world == 1 else f"hash-sharded x{world}, one all-to-all ({backend})",
                 "device": info["name"],
                 "arch": info["arch"],
             },
-            "roofline": roofline(stats, n, n, args.steps) if stats else None,
+            "roofline": roofline(stats, n, n, args.steps, 8 if args.payload64 else 4) if stats else None,
         }
         if not distributed and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
