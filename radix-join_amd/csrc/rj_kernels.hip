@@ -4,11 +4,12 @@
 //   K0  page headers        4 B read per 8 KiB page
 //   K1  page decode         irregular (NULL-bearing) pages -> dense values + validity
 //   K2  pass histogram      per-workgroup LDS histogram, flushed once per tile group
-//   K3  bin scan            single workgroup, wave-shuffle scan
-//   K4  pass scatter        tile sorted by digit in LDS (LDS atomics give the rank), runs
-//                           written out contiguously = software write-combining
-//   K5/6 build + probe      per-partition linear-probing table in LDS, ballot/mbcnt
-//                           output offsets, one global reservation per 4096 probe tuples
+//   K3  bin scan            one workgroup per input segment, wave-shuffle scan
+//   K4  pass scatter        tile of 16384 tuples sorted by digit in LDS (LDS atomics give the
+//                           rank), runs written out contiguously = software write-combining
+//   K5/6 build + probe      per-partition bucketised hash table in LDS (one 16-byte read per
+//                           probe), ballot/mbcnt output offsets, one global reservation per
+//                           4096 probe tuples, streams written straight into Page images
 //   K7  gather              row-id -> column value (generic late materialisation)
 //   K8  page finish/encode  Page headers + validity bitmaps of the result
 //
@@ -649,14 +650,16 @@ __global__ void k_heavy_tasks(const uint32_t* offR, const uint32_t* offS, uint32
 
 // ========================================================== K5/K6 build + probe
 // Replaces the per-bucket table of the reference (src/execute.cpp:203-248):
-//   build  — linear probing in LDS, slot claimed with one LDS compare-and-swap;
-//            duplicate build keys simply occupy further slots of the same run;
-//   probe  — walk the run until the EMPTY marker, every equal key is a match
-//            (so duplicates multiply, reference :232-243);
+//   build  — bucketised table in LDS: a tuple takes the next free slot of its 4-slot home
+//            bucket (one LDS counter atomic), a full bucket overflows into the next one;
+//            duplicate build keys simply occupy further slots;
+//   probe  — one 16-byte read per bucket, four register compares; a bucket whose last slot
+//            is EMPTY ends the walk; every equal key is a match (so duplicates multiply,
+//            reference :232-243);
 //   emit   — ballot/mbcnt offsets inside the wave, one global atomic per 4096
 //            probe tuples reserves the output rows; lanes of a wave then write
 //            consecutive rows of each output stream (coalesced).
-// Slot index uses hash bits ABOVE the radix bits (the reference reuses the low
+// Bucket index uses hash bits ABOVE the radix bits (the reference reuses the low
 // bits for both, SURVEY.md §3.2 — not copied).  EMPTY is a word whose radix bits
 // differ from the partition's, so it cannot collide with a stored hashed key.
 // A build partition larger than JN_RMAX is processed in table-sized chunks
@@ -1090,11 +1093,6 @@ __global__ __launch_bounds__(256) void k_encode_nullable(const uint8_t* values, 
     }
 }
 
-__global__ void k_unhash32(uint32_t* keys, uint64_t n) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) keys[i] = unfmix32(keys[i]);
-}
-
 // ================================================================== launchers
 #define RJ_KLAUNCH(L, NAME, KERNEL, GRID, BLOCK, ...)                         \
     do {                                                                      \
@@ -1291,11 +1289,6 @@ void launch_encode_nullable(const Launch& L, const uint8_t* values, const uint8_
     else
         RJ_KLAUNCH(L, "encode_nullable", (k_encode_nullable<8>), np, 256, values, valid, n_rows,
                    pages);
-}
-
-void launch_unhash32(const Launch& L, uint32_t* keys, uint64_t n) {
-    if (!n) return;
-    RJ_KLAUNCH(L, "unhash", k_unhash32, (uint32_t)((n + 255) / 256), 256, keys, n);
 }
 
 }  // namespace rj

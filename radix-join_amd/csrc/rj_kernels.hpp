@@ -60,6 +60,5 @@ void launch_gather(const Launch& L, const ColRef& src, const uint32_t* idx, uint
 void launch_finish_pages(const Launch& L, uint8_t* pages, uint64_t n_rows, int width);
 void launch_encode_nullable(const Launch& L, const uint8_t* values, const uint8_t* valid,
                             uint64_t n_rows, int width, uint8_t* pages);
-void launch_unhash32(const Launch& L, uint32_t* keys, uint64_t n);
 
 }  // namespace rj
