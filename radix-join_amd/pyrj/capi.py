@@ -294,12 +294,17 @@ class Context:
             del keep
 
     def execute_resident(self, plan: pl.Plan, tables, keep_on_device=True) -> Result:
-        cplan, keep = pl.plan_to_c(plan, with_inputs=False)
+        # the flattened plan is cached on the Plan object (callers that run one plan many
+        # times, like bench.py, should not re-marshal it every step)
+        cached = getattr(plan, "_c_resident", None)
+        if cached is None:
+            cached = pl.plan_to_c(plan, with_inputs=False)
+            plan._c_resident = cached
+        cplan, keep = cached
         hs = (C.c_void_p * max(1, len(tables)))(*[t.h for t in tables])
         out = C.c_void_p()
         flags = RJ_EXEC_KEEP_ON_DEVICE if keep_on_device else 0
         self._check(self.L.rj_execute_resident(self.h, C.byref(cplan), hs, len(tables), flags, C.byref(out)))
-        del keep
         return Result(self, out)
 
     # -- sharded path
