@@ -72,6 +72,58 @@ def make_tables(schema, seed=0, scale=1.0):
     return out
 
 
+REAL_ROWS = {  # IMDB (JOB snapshot) cardinalities
+    "aka_name": 901343, "aka_title": 361472, "cast_info": 36244344, "char_name": 3140339, "comp_cast_type": 4,
+    "company_name": 234997, "company_type": 4, "complete_cast": 135086, "info_type": 113, "keyword": 134170,
+    "kind_type": 7, "link_type": 18, "movie_companies": 2609129, "movie_info": 14835720, "movie_info_idx": 1380035,
+    "movie_keyword": 4523930, "movie_link": 29997, "name": 4167491, "person_info": 2963664, "role_type": 12,
+    "title": 2528312,
+}
+
+
+def make_scan_table(schema_cols, table, n, rng):
+    """One scan's (already filtered) input at realistic size, generated with vectorised numpy
+    only: `id` a random subset of the real id range, foreign keys uniform over the parent's real
+    id range, nullable INT32 columns with 5 % NULLs, VARCHAR columns fixed-length strings."""
+    from . import pages as pg
+
+    t = pl.ColumnarTable(n, [])
+    for name, typ, nullable in schema_cols:
+        if typ == "INT32":
+            if name == "id":
+                vals = rng.choice(REAL_ROWS[table], size=n, replace=False).astype(np.int32) if n < REAL_ROWS[table] else rng.permutation(n).astype(np.int32)
+            elif name in FK_PARENT:
+                vals = rng.integers(0, REAL_ROWS[FK_PARENT[name]], n).astype(np.int32)
+            else:
+                vals = rng.integers(1880, 2025, n).astype(np.int32)
+            valid = (rng.random(n) >= 0.05) if nullable else None
+            t.columns.append(pl.Column(pl.INT32, pg.pack_fixed(vals, valid, pl.INT32)))
+        else:
+            t.columns.append(pl.Column(pl.VARCHAR, pg.pack_varchar_fixed(np.arange(n), digits=9, prefix=name[:3].encode())))
+    return t
+
+
+def make_scaled_inputs(query, schema, rng, cache):
+    """alias -> ColumnarTable for every scan of `query`, sized by PostgreSQL's "Plan Rows"
+    estimate of that scan (x3 parallel workers when filtered, capped by the real cardinality;
+    the real cardinality when unfiltered).  `cache` shares tables between queries."""
+    tables = {}
+
+    def visit(tree):
+        if "scan" in tree:
+            n = max(1, min(REAL_ROWS[tree["scan"]], tree["rows"] * 3 if tree["filtered"] else REAL_ROWS[tree["scan"]]))
+            key = (tree["scan"], n)
+            if key not in cache:
+                cache[key] = make_scan_table(schema[tree["scan"]], tree["scan"], n, rng)
+            tables[tree["alias"]] = cache[key]
+        else:
+            visit(tree["left"])
+            visit(tree["right"])
+
+    visit(query["tree"])
+    return tables
+
+
 def _aliases(tree):
     return {tree["alias"]} if "scan" in tree else _aliases(tree["left"]) | _aliases(tree["right"])
 

@@ -28,3 +28,19 @@ def test_job_plan(ctx, name):
     assert got.num_rows == want.num_rows
     assert [c.type for c in got.columns] == [c.type for c in want.columns]
     assert pl.sorted_rows(got) == pl.sorted_rows(want)
+
+
+@pytest.mark.parametrize("name", ["1a", "13d"])
+def test_job_plans_at_scale(ctx, name):
+    """BASELINE configs 1 and 5 at realistic input sizes: every scan's input is sized by
+    PostgreSQL's Plan Rows estimate (pyrj.job.make_scaled_inputs; 3.9 M rows for 1a, 21.5 M for
+    13d).  GPU vs oracle: row count, and the rows themselves (results are small)."""
+    import numpy as np
+
+    rng = np.random.default_rng(7)
+    tables = job.make_scaled_inputs(FX["queries"][name], FX["schema"], rng, {})
+    p = job.build_plan(FX["queries"][name], FX["schema"], tables, by_alias=True)
+    got = capi.execute(p, ctx)
+    want = _oracle.execute(p)
+    assert got.num_rows == want.num_rows > 0
+    assert pl.sorted_rows(got) == pl.sorted_rows(want)
