@@ -683,8 +683,13 @@ enum { OM_GENERIC = 0, OM_PAGED32 = 1, OM_DENSE32 = 2 };
     } while (0)
 
 template <int KW, int CWR, int CWS, int OM>
-__global__ __launch_bounds__(JN_THREADS, jn_min_waves(KW + CWR)) void k_join(JoinParams jp) {
-    constexpr int      RW = KW + CWR;  // LDS table arrays (one per word)
+__global__ __launch_bounds__(JN_THREADS, jn_min_waves(KW + (CWR == 2 ? 1 : CWR))) void k_join(JoinParams jp) {
+    // A two-word build carry is NOT kept in the LDS table: the table then stores the build
+    // tuple's position instead and the carry words are fetched from the partitioned build
+    // arrays on emit (the partition's chunk was just streamed, so they come from L2).  That
+    // keeps the table at two arrays (two workgroups per CU) for INT64 payloads.
+    constexpr bool     IND = CWR == 2;
+    constexpr int      RW = KW + (IND ? 1 : CWR);  // LDS table arrays (one per word)
     constexpr int      SW = KW + CWS;
     // Bucketised table: JN_CAP slots = JN_CAP/4 buckets of 4 consecutive slots.  A probe
     // reads a whole bucket with ONE 16-byte LDS read and compares in registers, an insert
@@ -735,12 +740,13 @@ __global__ __launch_bounds__(JN_THREADS, jn_min_waves(KW + CWR)) void k_join(Joi
     uint32_t rw[JN_RPT][RW];
     uint32_t sw[JN_SPT][SW];
     auto load_build = [&](uint32_t rc, uint32_t rn) {
+        constexpr int LW = IND ? KW : RW;  // words actually read from the build arrays
 #pragma unroll
         for (int v = 0; v < JN_RPT / 4; ++v) {
             const uint32_t i0 = (v * JN_THREADS + threadIdx.x) * 4;
             if (i0 + 3 < rn) {
 #pragma unroll
-                for (int a = 0; a < RW; ++a) {
+                for (int a = 0; a < LW; ++a) {
                     u32x4a x = *reinterpret_cast<const u32x4a*>(jp.R.w[a] + rc + i0);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) rw[4 * v + e][a] = x[e];
@@ -749,8 +755,12 @@ __global__ __launch_bounds__(JN_THREADS, jn_min_waves(KW + CWR)) void k_join(Joi
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int a = 0; a < RW; ++a)
+                    for (int a = 0; a < LW; ++a)
                         rw[4 * v + e][a] = i0 + e < rn ? jp.R.w[a][rc + i0 + e] : 0u;
+            }
+            if constexpr (IND) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rw[4 * v + e][KW] = rc + i0 + e;  // build position
             }
         }
     };
@@ -954,8 +964,15 @@ __global__ __launch_bounds__(JN_THREADS, jn_min_waves(KW + CWR)) void k_join(Joi
                     for (int j = 0; j < JN_SPT; ++j) {
                         c0[j] = 0;
                         c1[j] = 0;
-                        if constexpr (CWR >= 1) c0[j] = m[j] ? t_w[KW][f[j]] : 0u;
-                        if constexpr (CWR == 2) c1[j] = m[j] ? t_w[KW + 1][f[j]] : 0u;
+                        if constexpr (IND) {
+                            if (m[j]) {
+                                const uint32_t pos = t_w[KW][f[j]];
+                                c0[j] = jp.R.w[KW][pos];
+                                c1[j] = jp.R.w[KW + 1][pos];
+                            }
+                        } else {
+                            if constexpr (CWR >= 1) c0[j] = m[j] ? t_w[KW][f[j]] : 0u;
+                        }
                     }
 #pragma unroll
                     for (int j = 0; j < JN_SPT; ++j) {
@@ -981,8 +998,15 @@ __global__ __launch_bounds__(JN_THREADS, jn_min_waves(KW + CWR)) void k_join(Joi
                             if (KW == 2) eq = eq && t_w[KW - 1][slot] == sw[j][KW - 1];
                             if (eq) {
                                 ++row;
-                                emit_row(row, klo, khi, CWR >= 1 ? t_w[KW < RW ? KW : 0][slot] : 0u,
-                                         CWR == 2 ? t_w[RW - 1][slot] : 0u, p0, p1);
+                                uint32_t b0 = 0, b1 = 0;
+                                if constexpr (IND) {
+                                    const uint32_t pos = t_w[KW][slot];
+                                    b0 = jp.R.w[KW][pos];
+                                    b1 = jp.R.w[KW + 1][pos];
+                                } else if constexpr (CWR >= 1) {
+                                    b0 = t_w[KW][slot];
+                                }
+                                emit_row(row, klo, khi, b0, b1, p0, p1);
                                 --left;
                             }
                             slot = (slot + 1) & SMASK;
