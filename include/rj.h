@@ -102,7 +102,8 @@ typedef struct rj_context rj_context;
 
 typedef struct rj_config {
     int32_t  device;      /* HIP device ordinal; -1 = current device          */
-    int32_t  profile;     /* !=0: bracket every kernel with HIP events        */
+    int32_t  profile;     /* 1: HIP events around the data-moving kernels,
+                             2: around every launch; 0: none                   */
     void*    stream;      /* hipStream_t to launch on; NULL = library-owned   */
     int32_t  radix_bits;  /* total radix bits; 0 = auto from build cardinality */
     int32_t  reserved0;

@@ -57,6 +57,7 @@ int rj_context_create(rj_context** out, const rj_config* cfg) {
             c->own_stream = true;
         }
         c->prof.on = cfg && cfg->profile;
+        c->prof.level = cfg && cfg->profile >= 2 ? 2 : 1;
         c->prof.stream = c->stream;
         c->radix_bits_override = cfg ? cfg->radix_bits : 0;
         *out = c.release();

@@ -538,8 +538,9 @@ class Exec {
 
         uint64_t cap = std::max(left.n, right.n);
         cap = std::min<uint64_t>(cap + 1024, 0xfffffff0ull);
-        BufP     key_stream;
-        uint64_t nrows = 0;
+        BufP            key_stream;
+        uint64_t        nrows = 0;
+        std::set<void*> finished;  // paged buffers that already got their headers
         for (int attempt = 0; attempt < 2; ++attempt) {
             key_stream = key_mode != ST_NONE ? ctx->buf(stream_bytes(key_mode, cap)) : BufP();
             for (Side* s : {&ls, &rs})
@@ -586,6 +587,25 @@ class Exec {
             }
             jp.heavy_pass = 1;
             launch_join(L, KW, bs.CW, ps.CW, jp, max_tasks);
+            // Page headers of the streams the probe wrote straight into Page images: done on
+            // the device from the device-side row count, so nothing waits for the read-back
+            finished.clear();
+            {
+                uint8_t* fp[3];
+                int      fw[3];
+                uint32_t nf = 0;
+                auto add = [&](const BufP& b, int mode) {
+                    if (!b || (mode != ST_PAGED32 && mode != ST_PAGED64) || finished.count(b->p)) return;
+                    fp[nf] = b->as<uint8_t>();
+                    fw[nf] = mode == ST_PAGED32 ? 4 : 8;
+                    ++nf;
+                    finished.insert(b->p);
+                };
+                add(key_stream, key_mode);
+                add(ls.stream, ls.stream_mode);
+                add(rs.stream, rs.stream_mode);
+                launch_finish_streams(L, fp, fw, nf, counters->as<unsigned long long>(), cap);
+            }
             unsigned long long h = 0;
             RJ_HIP(hipMemcpyAsync(&h, counters->p, 8, hipMemcpyDeviceToHost, ctx->stream));
             ctx->sync();
@@ -601,7 +621,6 @@ class Exec {
         Rel out;
         out.n = nrows;
         if (is_root) root_res->num_rows = nrows;
-        std::set<void*> finished;  // paged buffers that already got headers
         for (size_t k = 0; k < js.out_idx.size(); ++k) {
             bool        is_left = js.out_idx[k] < lw;
             Side&       s = is_left ? ls : rs;

@@ -86,6 +86,7 @@ using BufP = std::shared_ptr<Buf>;
 class Profiler {
    public:
     bool        on = false;
+    int         level = 1;  // 1: hot kernels only, 2: every launch
     hipStream_t stream = nullptr;
     void        begin(const char* name);
     void        end();
@@ -106,6 +107,7 @@ class Profiler {
     };
     std::vector<Rec>        open_;
     std::vector<hipEvent_t> spare_;
+    bool                    skip_ = false;
     hipEvent_t              get_event();
 };
 

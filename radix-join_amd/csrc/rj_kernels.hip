@@ -16,6 +16,8 @@
 // Reference counterparts are cited at each kernel (paths relative to the reference).
 #include "rj_kernels.hpp"
 
+#include <algorithm>
+
 namespace rj {
 
 // ============================================================== small helpers
@@ -1064,6 +1066,36 @@ __global__ __launch_bounds__(256) void k_finish_pages(uint8_t* pages, uint64_t n
     }
 }
 
+// Same, for the (up to three) streams the probe kernel wrote, with the row count still on
+// the device: launched right behind the probe, before the host reads the count back.
+struct FinishStreams {
+    uint8_t* pages[3];
+    uint32_t rows_full[3];
+    uint32_t n;
+};
+__global__ __launch_bounds__(256) void k_finish_streams(FinishStreams fs,
+                                                        const unsigned long long* n_rows_dev,
+                                                        uint64_t cap_rows) {
+    const uint64_t n_rows = *n_rows_dev;
+    if (n_rows > cap_rows) return;  // overflow: the host re-runs the probe with larger buffers
+    const uint32_t b = blockIdx.y;
+    const uint32_t rf = fs.rows_full[b];
+    const uint64_t first = (uint64_t)blockIdx.x * rf;
+    if (first >= n_rows) return;
+    uint8_t*       page = fs.pages[b] + (size_t)blockIdx.x * PAGE_BYTES;
+    const uint32_t nr = (uint32_t)min((uint64_t)rf, n_rows - first);
+    const uint32_t nb = (nr + 7) / 8;
+    if (threadIdx.x == 0) {
+        reinterpret_cast<uint16_t*>(page)[0] = (uint16_t)nr;
+        reinterpret_cast<uint16_t*>(page)[1] = (uint16_t)nr;
+    }
+    uint8_t* bm = page + PAGE_BYTES - nb;
+    for (uint32_t k = threadIdx.x; k < nb; k += blockDim.x) {
+        uint32_t bits = nr - k * 8u;
+        bm[k] = bits >= 8 ? 0xff : (uint8_t)((1u << bits) - 1u);
+    }
+}
+
 // Result pages of a column that carries NULLs: a fixed rows_full rows per page
 // (any fill that satisfies the layout decodes to the same rows), values packed
 // densely in row order, bitmap at the tail.
@@ -1300,6 +1332,21 @@ void launch_finish_pages(const Launch& L, uint8_t* pages, uint64_t n_rows, int w
     uint32_t rf = width == 4 ? ROWS32 : ROWS64;
     uint32_t np = (uint32_t)((n_rows + rf - 1) / rf);
     RJ_KLAUNCH(L, "finish_pages", k_finish_pages, np, 256, pages, n_rows, rf);
+}
+
+void launch_finish_streams(const Launch& L, uint8_t* const* pages, const int* widths, uint32_t n,
+                           const unsigned long long* n_rows_dev, uint64_t cap_rows) {
+    if (!n || !cap_rows) return;
+    FinishStreams fs{};
+    fs.n = n;
+    uint64_t max_pages = 0;
+    for (uint32_t i = 0; i < n && i < 3; ++i) {
+        fs.pages[i] = pages[i];
+        fs.rows_full[i] = widths[i] == 4 ? ROWS32 : ROWS64;
+        max_pages = std::max<uint64_t>(max_pages, (cap_rows + fs.rows_full[i] - 1) / fs.rows_full[i]);
+    }
+    RJ_KLAUNCH(L, "finish_pages", k_finish_streams, dim3((uint32_t)max_pages, n), 256, fs, n_rows_dev,
+               cap_rows);
 }
 
 void launch_encode_nullable(const Launch& L, const uint8_t* values, const uint8_t* valid,

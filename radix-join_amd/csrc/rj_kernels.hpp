@@ -58,6 +58,9 @@ void launch_join(const Launch& L, int key_words, int cw_build, int cw_probe, con
 void launch_gather(const Launch& L, const ColRef& src, const uint32_t* idx, uint64_t n,
                    const OutStream& dst, uint8_t* dst_valid);
 void launch_finish_pages(const Launch& L, uint8_t* pages, uint64_t n_rows, int width);
+// headers + bitmaps of up to three probe-written streams, row count read on the device
+void launch_finish_streams(const Launch& L, uint8_t* const* pages, const int* widths, uint32_t n,
+                           const unsigned long long* n_rows_dev, uint64_t cap_rows);
 void launch_encode_nullable(const Launch& L, const uint8_t* values, const uint8_t* valid,
                             uint64_t n_rows, int width, uint8_t* pages);
 
