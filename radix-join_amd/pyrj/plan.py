@@ -153,6 +153,18 @@ def sorted_rows(t: ColumnarTable):
     return sorted(table_rows(t), key=_sort_key)
 
 
+def canonical_rows(t: ColumnarTable):
+    """sorted_rows with floats replaced by their bit patterns, so that NaN payloads (and
+    -0.0 / +0.0) compare by identity of the stored value — for differential tests."""
+    import struct
+
+    def canon(v):
+        return ("f64", struct.unpack("<q", struct.pack("<d", v))[0]) if isinstance(v, float) else v
+
+    rows = [tuple(canon(v) for v in r) for r in table_rows(t)]
+    return sorted(rows, key=lambda r: tuple((2, 0) if v is None else ((1, v[1]) if isinstance(v, tuple) else (0, v)) for v in r))
+
+
 def table_digest(t: ColumnarTable):
     """Order-independent digest of a fixed-width table: (rows, sum, xor) of a
     64-bit row hash — for sizes where sorting rows in Python is too slow."""
