@@ -159,22 +159,44 @@ int rj_execute(rj_context* ctx, const rj_plan* plan, rj_result** out) {
         const char* dg = getenv("RJ_DIAG");
         const bool  diag = dg && atoi(dg) >= 2;
         auto        t0 = std::chrono::steady_clock::now();
-        std::vector<std::unique_ptr<Table>> owned(plan->n_inputs);
-        std::vector<Table*>                 ts(plan->n_inputs, nullptr);
-        rj_input                            none{};
-        for (uint64_t i = 0; i < plan->n_inputs; ++i) {
-            owned[i].reset(table_upload(ctx, used[i] ? &plan->inputs[i] : &none,
-                                        used[i] ? &col_used[i] : nullptr, /*borrow_varchar=*/true));
-            ts[i] = owned[i].get();
+        const uint64_t m0 = ctx->pool.n_malloc, tr0 = ctx->pool.n_trim;
+        const double   mm0 = ctx->pool.malloc_ms;
+        auto        ms_since = [](std::chrono::steady_clock::time_point t) {
+            return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+        };
+        const char* su = getenv("RJ_SYNC_UPLOAD");
+        if (su && atoi(su) > 0) {  // diagnostic: upload everything, then run the plan
+            std::vector<std::unique_ptr<Table>> owned(plan->n_inputs);
+            std::vector<Table*>                 ts(plan->n_inputs, nullptr);
+            rj_input                            none{};
+            for (uint64_t i = 0; i < plan->n_inputs; ++i) {
+                owned[i].reset(table_upload(ctx, used[i] ? &plan->inputs[i] : &none,
+                                            used[i] ? &col_used[i] : nullptr, /*borrow_varchar=*/true));
+                ts[i] = owned[i].get();
+            }
+            double up = ms_since(t0);
+            *out = static_cast<rj_result*>(execute_plan(ctx, plan, ts.data(), plan->n_inputs, 0));
+            if (diag)
+                fprintf(stderr, "[rj host] upload %.2f ms, then plan (device + host VARCHAR) %.2f ms\n", up,
+                        ms_since(t0) - up);
+            return;
         }
-        auto t1 = std::chrono::steady_clock::now();
-        *out = static_cast<rj_result*>(execute_plan(ctx, plan, ts.data(), plan->n_inputs, 0));
-        if (diag) {
-            auto   t2 = std::chrono::steady_clock::now();
-            double up = std::chrono::duration<double, std::milli>(t1 - t0).count();
-            double ex = std::chrono::duration<double, std::milli>(t2 - t1).count();
-            fprintf(stderr, "[rj host] upload %.2f ms, plan (device + host VARCHAR) %.2f ms\n", up, ex);
+        // the plan starts at once; every ScanNode waits only for its own base table
+        AsyncUpload  upl(ctx, plan, used, col_used);
+        try {
+            *out = static_cast<rj_result*>(execute_plan(ctx, plan, nullptr, plan->n_inputs, 0, &upl));
+        } catch (...) {
+            // kernels queued on the stream may still read the tables `upl` is about to release
+            (void)hipStreamSynchronize(ctx->stream);
+            throw;
         }
+        if (diag)
+            fprintf(stderr,
+                    "[rj host] execute %.2f ms (plan walk blocked on uploads for %.2f ms); HBM cache: %llu "
+                    "hipMalloc %.2f ms, %llu trims, %.1f GB in use, %.1f GB cached\n",
+                    ms_since(t0), upl.wait_ms(), (unsigned long long)(ctx->pool.n_malloc - m0),
+                    ctx->pool.malloc_ms - mm0, (unsigned long long)(ctx->pool.n_trim - tr0),
+                    ctx->pool.bytes_in_use() / 1e9, ctx->pool.bytes_cached() / 1e9);
     });
 }
 

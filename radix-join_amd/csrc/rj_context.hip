@@ -1,4 +1,6 @@
 // rj_context.hip — context, HBM block cache, HIP-event profiler.
+#include <chrono>
+
 #include "rj_internal.hpp"
 
 namespace rj {
@@ -26,16 +28,20 @@ void* DevPool::alloc(size_t bytes) {
         return blocks_[best].p;
     }
     void*      p = nullptr;
+    auto       t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(&p, need);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         trim();
+        ++n_trim;
         e = hipMalloc(&p, need);
         if (e != hipSuccess) {
             (void)hipGetLastError();
             throw_fmt(RJ_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", need, hipGetErrorString(e));
         }
     }
+    ++n_malloc;
+    malloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     blocks_.push_back({p, need, false});
     in_use_ += need;
     return p;
@@ -154,8 +160,29 @@ void* Context::staging(size_t bytes) {
     return pinned;
 }
 
+hipStream_t Context::upload_stream() {
+    if (!copy_stream) RJ_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+    return copy_stream;
+}
+
+void* Context::upload_staging(size_t bytes) {
+    if (bytes > pinned_up_bytes) {
+        if (pinned_up) (void)hipHostFree(pinned_up);
+        pinned_up = nullptr;
+        pinned_up_bytes = 0;
+        RJ_HIP(hipHostMalloc(&pinned_up, bytes, hipHostMallocDefault));
+        pinned_up_bytes = bytes;
+    }
+    return pinned_up;
+}
+
 Context::~Context() {
     if (stream) (void)hipStreamSynchronize(stream);
+    if (copy_stream) {
+        (void)hipStreamSynchronize(copy_stream);
+        (void)hipStreamDestroy(copy_stream);
+    }
+    if (pinned_up) (void)hipHostFree(pinned_up);
     if (pinned) (void)hipHostFree(pinned);
     if (pinned_small) (void)hipHostFree(pinned_small);
     if (own_stream && stream) (void)hipStreamDestroy(stream);

@@ -71,6 +71,7 @@ class Exec {
    public:
     Exec(Context* c, const rj_plan* p, Table* const* t, uint64_t nt, int fl)
         : ctx(c), plan(p), tables(t), n_tables(nt), flags(fl), L(c->launch()) {}
+    void set_fetch(TableFetch* f) { fetch = f; }
 
     Result* run() {
         if (!plan || plan->root >= plan->n_nodes) throw_fmt(RJ_ERR_ARG, "bad plan root");
@@ -155,6 +156,7 @@ class Exec {
     Table* const*  tables;
     uint64_t       n_tables;
     int            flags;
+    TableFetch*    fetch = nullptr;
     Launch         L;
     std::map<std::pair<const Table*, int>, DCol> decoded_;
     std::map<std::pair<int, int>, std::vector<uint64_t>> vc_dir_;  // VARCHAR page directories
@@ -202,8 +204,11 @@ class Exec {
     }
 
     const Table* table_of(const rj_node& n) {
-        if (n.base_table_id >= n_tables) throw_fmt(RJ_ERR_ARG, "scan: bad base_table_id");
-        return tables[n.base_table_id];
+        return table_by_id(n.base_table_id);
+    }
+    const Table* table_by_id(uint64_t id) {
+        if (id >= n_tables) throw_fmt(RJ_ERR_ARG, "scan: bad base_table_id");
+        return fetch ? fetch->get(id) : tables[id];
     }
 
     // execute_scan (reference src/execute.cpp:284-300): column selection, zero copy
@@ -716,7 +721,7 @@ class Exec {
     void varchar_root(const uint32_t* dev_rowids, uint64_t n, const DCol& src, ResultColumn& rc) {
         if (src.vc_table < 0 || (uint64_t)src.vc_table >= n_tables)
             throw_fmt(RJ_ERR_ARG, "VARCHAR column without provenance");
-        const Table*       t = tables[src.vc_table];
+        const Table*       t = table_by_id((uint64_t)src.vc_table);
         const TableColumn& tc = t->cols[src.vc_col];
         const bool diag = tune("RJ_DIAG", 0) >= 2;
         auto       tv0 = std::chrono::steady_clock::now();
@@ -745,8 +750,9 @@ class Exec {
 }  // namespace
 
 Result* execute_plan(Context* ctx, const rj_plan* plan, Table* const* tables, uint64_t n_tables,
-                     int flags) {
+                     int flags, TableFetch* fetch) {
     Exec e(ctx, plan, tables, n_tables, flags);
+    e.set_fetch(fetch);
     return e.run();
 }
 

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -53,6 +54,9 @@ class DevPool {
     ~DevPool();
     size_t bytes_in_use() const { return in_use_; }
     size_t bytes_cached() const { return cached_; }
+    // diagnostics (RJ_DIAG=2): what went to the driver instead of the cache
+    uint64_t n_malloc = 0, n_trim = 0;
+    double   malloc_ms = 0;
 
    private:
     struct Block {
@@ -121,6 +125,7 @@ struct TableColumn {
     bool           regular = false; // addressable in place (see ColKind::COL_PAGED)
     uint64_t       page_rows_total = 0;
     BufP           page_rows;      // u32[n_pages] rows per page (for K1)
+    std::vector<uint32_t> page_rows_host;  // the same, read off the headers while uploading
     // VARCHAR columns stay on the host: vc_pages[i] points at page i — into `host_pages`
     // (a private copy, resident tables) or into the caller's pages (rj_execute, where the
     // Plan's inputs outlive the call)
@@ -162,6 +167,13 @@ struct Context {
     void*  pinned = nullptr;
     size_t pinned_bytes = 0;
     void*  pinned_small = nullptr;  // 4 KiB for counters
+    // second lane (rj_execute): inputs are uploaded by a helper thread on their own stream
+    // while the plan already runs on `stream`
+    hipStream_t copy_stream = nullptr;
+    void*       pinned_up = nullptr;
+    size_t      pinned_up_bytes = 0;
+    hipStream_t upload_stream();
+    void*       upload_staging(size_t bytes);
     Launch launch() {
         Launch L;
         L.stream = stream;
@@ -178,9 +190,17 @@ struct Context {
     ~Context();
 };
 
+// Where a ScanNode gets its base table from: a plain array (resident tables) or the
+// asynchronous uploader, whose get() blocks until that table has landed in HBM.
+struct TableFetch {
+    virtual Table* get(uint64_t id) = 0;
+    virtual ~TableFetch() = default;
+};
+
 // rj_exec.hip
+// tables: n_tables resident tables, or nullptr when `fetch` delivers them
 Result* execute_plan(Context* ctx, const rj_plan* plan, Table* const* tables, uint64_t n_tables,
-                     int flags);
+                     int flags, TableFetch* fetch = nullptr);
 Result* join_tuples(Context* ctx, const rj_tuples* build, const rj_tuples* probe,
                     uint32_t skip_rank_bits, int flags);
 void    shard_partition(Context* ctx, const Table* t, uint64_t key_col, uint64_t carry_col,
@@ -191,9 +211,31 @@ void    shard_partition(Context* ctx, const Table* t, uint64_t key_col, uint64_t
 // caller's VARCHAR pages instead of copying them
 Table* table_upload(Context* ctx, const rj_input* host, const std::vector<bool>* col_used = nullptr,
                     bool borrow_varchar = false);
+// All inputs of a Plan, uploaded by a helper thread in the order the plan walk scans them
+// (rj_execute).  HBM is reserved up front on the caller's thread; the helper only gathers,
+// copies and reads page headers, so the block cache stays single-threaded.
+class AsyncUpload : public TableFetch {
+   public:
+    AsyncUpload(Context* ctx, const rj_plan* plan, const std::vector<bool>& used,
+                const std::vector<std::vector<bool>>& col_used);
+    ~AsyncUpload() override;
+    Table* get(uint64_t id) override;
+    double busy_ms() const { return busy_ms_; }   // helper thread: gather + H2D
+    double wait_ms() const { return wait_ms_; }   // plan walk: blocked in get()
+
+   private:
+    struct Impl;
+    std::unique_ptr<Impl> im_;
+    double                busy_ms_ = 0, wait_ms_ = 0;
+};
 Table* table_adopt(Context* ctx, uint64_t num_rows, uint64_t n_cols, const int32_t* types,
                    const void* const* dev_pages, const uint64_t* n_pages);
 void   result_copy_pages(Result* r, uint64_t col, void* const* dst, uint64_t n_dst);
+
+// rj_hostpool.cpp (host only)
+// fn(b, e) over disjoint ranges of at most `grain` items covering [0, n), on the process-wide
+// worker threads plus the caller; the first exception thrown by fn is rethrown here.
+void parallel_for(size_t n, size_t grain, const std::function<void(size_t, size_t)>& fn);
 
 // rj_varchar.cpp (host only)
 // Page directory of a VARCHAR column: row_base[p] = rows before page p, row_base[n_pages] =

@@ -5,7 +5,11 @@
 // 8 KiB host blocks (include/plan.h:64-68), neither pinned nor contiguous, so
 // they are gathered into pinned staging and copied to HBM in 32 MiB chunks.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
 #include <thread>
 
 #include "rj_internal.hpp"
@@ -13,24 +17,6 @@
 namespace rj {
 
 static constexpr size_t CHUNK_PAGES = 4096;  // 32 MiB per staging half
-
-static void parallel_for(size_t n, size_t grain, const std::function<void(size_t, size_t)>& fn) {
-    unsigned hw = std::thread::hardware_concurrency();
-    size_t   nt = std::min<size_t>(hw ? hw : 4, 16);
-    nt = std::min(nt, (n + grain - 1) / grain);
-    if (nt <= 1) {
-        fn(0, n);
-        return;
-    }
-    std::vector<std::thread> th;
-    size_t                   per = (n + nt - 1) / nt;
-    for (size_t t = 0; t < nt; ++t) {
-        size_t b = t * per, e = std::min(n, b + per);
-        if (b >= e) break;
-        th.emplace_back([=, &fn] { fn(b, e); });
-    }
-    for (auto& t : th) t.join();
-}
 
 // Header scan of one fixed-width column that already sits in HBM.
 static void analyse_column(Context* ctx, TableColumn& c, uint64_t num_rows) {
@@ -80,8 +66,34 @@ Table* table_adopt(Context* ctx, uint64_t num_rows, uint64_t n_cols, const int32
     return t.release();
 }
 
-Table* table_upload(Context* ctx, const rj_input* in, const std::vector<bool>* col_used,
-                    bool borrow_varchar) {
+// ---- upload = prepare (caller's thread: shape the Table, reserve HBM) + fill (any thread:
+//      gather into pinned staging, H2D in 32 MiB chunks, page headers read on the way)
+namespace {
+
+struct UploadLane {
+    hipStream_t stream = nullptr;
+    uint8_t*    stage = nullptr;  // 2 * CHUNK_PAGES pages of pinned memory
+    hipEvent_t  ev[2] = {nullptr, nullptr};
+    bool        used[2] = {false, false};
+    int         half = 0;
+    UploadLane(hipStream_t s, void* pinned) : stream(s), stage(static_cast<uint8_t*>(pinned)) {
+        RJ_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+        if (hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) != hipSuccess) {
+            (void)hipEventDestroy(ev[0]);
+            throw Error(RJ_ERR_DEVICE, "hipEventCreate failed");
+        }
+    }
+    ~UploadLane() {
+        (void)hipStreamSynchronize(stream);  // nothing may still read the staging buffer
+        (void)hipEventDestroy(ev[0]);
+        (void)hipEventDestroy(ev[1]);
+    }
+    UploadLane(const UploadLane&) = delete;
+    UploadLane& operator=(const UploadLane&) = delete;
+};
+
+Table* table_prepare(Context* ctx, const rj_input* in, const std::vector<bool>* col_used,
+                     bool borrow_varchar) {
     if (!in) throw_fmt(RJ_ERR_ARG, "null input");
     if (in->num_rows > 0xfffffff0ull)
         throw_fmt(RJ_ERR_UNSUPPORTED, "more than 2^32 rows in one table");
@@ -89,72 +101,216 @@ Table* table_upload(Context* ctx, const rj_input* in, const std::vector<bool>* c
     t->ctx = ctx;
     t->num_rows = in->num_rows;
     t->cols.resize(in->n_cols);
-    uint8_t* stage = static_cast<uint8_t*>(ctx->staging(2 * CHUNK_PAGES * PAGE_BYTES));
-    hipEvent_t ev[2];
-    RJ_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
-    RJ_HIP(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
-    bool used[2] = {false, false};
-    int  half = 0;
-    try {
-        for (uint64_t ci = 0; ci < in->n_cols; ++ci) {
-            const rj_column& hc = in->cols[ci];
-            TableColumn&     c = t->cols[ci];
-            c.type = hc.type;
-            c.n_pages = hc.n_pages;
-            if (c.type < RJ_INT32 || c.type > RJ_VARCHAR) throw_fmt(RJ_ERR_ARG, "bad column type");
-            if (col_used && !(*col_used)[ci]) {  // no ScanNode outputs this column
-                c.skipped = true;
-                c.n_pages = 0;
-                continue;
-            }
-            if (c.type == RJ_VARCHAR) {
-                const void* const* pages = hc.pages;
-                c.vc_pages.resize(hc.n_pages);
-                if (borrow_varchar) {
-                    for (uint64_t p = 0; p < hc.n_pages; ++p)
-                        c.vc_pages[p] = static_cast<const uint8_t*>(pages[p]);
-                } else {
-                    c.host_pages.resize(hc.n_pages * PAGE_BYTES);
-                    uint8_t* dst = c.host_pages.data();
-                    parallel_for(hc.n_pages, 256, [&](size_t b, size_t e) {
-                        for (size_t p = b; p < e; ++p) {
-                            memcpy(dst + p * PAGE_BYTES, pages[p], PAGE_BYTES);
-                            c.vc_pages[p] = dst + p * PAGE_BYTES;
-                        }
-                    });
-                }
-                continue;
-            }
-            if (hc.n_pages == 0) continue;
-            c.owned = ctx->buf(hc.n_pages * PAGE_BYTES);
-            c.dev_pages = c.owned->as<uint8_t>();
-            for (uint64_t p0 = 0; p0 < hc.n_pages; p0 += CHUNK_PAGES) {
-                uint64_t np = std::min<uint64_t>(CHUNK_PAGES, hc.n_pages - p0);
-                uint8_t* s = stage + (size_t)half * CHUNK_PAGES * PAGE_BYTES;
-                if (used[half]) RJ_HIP(hipEventSynchronize(ev[half]));
-                const void* const* pages = hc.pages + p0;
-                parallel_for(np, 256, [&](size_t b, size_t e) {
-                    for (size_t p = b; p < e; ++p) memcpy(s + p * PAGE_BYTES, pages[p], PAGE_BYTES);
-                });
-                RJ_HIP(hipMemcpyAsync(c.owned->as<uint8_t>() + p0 * PAGE_BYTES, s, np * PAGE_BYTES,
-                                      hipMemcpyHostToDevice, ctx->stream));
-                RJ_HIP(hipEventRecord(ev[half], ctx->stream));
-                used[half] = true;
-                half ^= 1;
-            }
+    for (uint64_t ci = 0; ci < in->n_cols; ++ci) {
+        const rj_column& hc = in->cols[ci];
+        TableColumn&     c = t->cols[ci];
+        c.type = hc.type;
+        c.n_pages = hc.n_pages;
+        if (c.type < RJ_INT32 || c.type > RJ_VARCHAR) throw_fmt(RJ_ERR_ARG, "bad column type");
+        if (col_used && !(*col_used)[ci]) {  // no ScanNode outputs this column
+            c.skipped = true;
+            c.n_pages = 0;
+            continue;
         }
-        ctx->sync();
-        for (TableColumn& c : t->cols)
-            if (c.type != RJ_VARCHAR && !c.skipped) analyse_column(ctx, c, t->num_rows);
-    } catch (...) {
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipEventDestroy(ev[0]);
-        (void)hipEventDestroy(ev[1]);
-        throw;
+        if (hc.n_pages && !hc.pages) throw_fmt(RJ_ERR_ARG, "null page pointer");
+        if (c.type == RJ_VARCHAR) {
+            c.vc_pages.resize(hc.n_pages);
+            if (borrow_varchar)
+                for (uint64_t p = 0; p < hc.n_pages; ++p)
+                    c.vc_pages[p] = static_cast<const uint8_t*>(hc.pages[p]);
+            else
+                c.host_pages.resize(hc.n_pages * PAGE_BYTES);
+            continue;
+        }
+        if (hc.n_pages == 0) continue;
+        if (hc.n_pages > 0xffffffffull) throw_fmt(RJ_ERR_UNSUPPORTED, "column has too many pages");
+        c.owned = ctx->buf(hc.n_pages * PAGE_BYTES);
+        c.dev_pages = c.owned->as<uint8_t>();
+        c.page_rows = ctx->buf(hc.n_pages * 4);
+        c.page_rows_host.resize(hc.n_pages);
     }
-    (void)hipEventDestroy(ev[0]);
-    (void)hipEventDestroy(ev[1]);
     return t.release();
+}
+
+// The header walk of Table::from_columnar (reference src/build_table.cpp:326-336) rides on the
+// gather: rows per page, whether the column is "regular", and the "row_idx" check.
+void table_fill(Table* t, const rj_input* in, UploadLane& lane) {
+    for (uint64_t ci = 0; ci < in->n_cols; ++ci) {
+        const rj_column& hc = in->cols[ci];
+        TableColumn&     c = t->cols[ci];
+        if (c.skipped) continue;
+        if (c.type == RJ_VARCHAR) {
+            if (c.host_pages.empty()) continue;  // borrowed, or no pages
+            uint8_t*           dst = c.host_pages.data();
+            const void* const* pages = hc.pages;
+            parallel_for(hc.n_pages, 256, [&](size_t b, size_t e) {
+                for (size_t p = b; p < e; ++p) {
+                    memcpy(dst + p * PAGE_BYTES, pages[p], PAGE_BYTES);
+                    c.vc_pages[p] = dst + p * PAGE_BYTES;
+                }
+            });
+            continue;
+        }
+        if (hc.n_pages == 0) continue;
+        const uint32_t        rows_full = c.type == RJ_INT32 ? ROWS32 : ROWS64;
+        std::atomic<uint64_t> irregular{0}, total{0};
+        uint32_t*             prow = c.page_rows_host.data();
+        for (uint64_t p0 = 0; p0 < hc.n_pages; p0 += CHUNK_PAGES) {
+            uint64_t np = std::min<uint64_t>(CHUNK_PAGES, hc.n_pages - p0);
+            uint8_t* s = lane.stage + (size_t)lane.half * CHUNK_PAGES * PAGE_BYTES;
+            if (lane.used[lane.half]) RJ_HIP(hipEventSynchronize(lane.ev[lane.half]));
+            const void* const* pages = hc.pages + p0;
+            parallel_for(np, 256, [&](size_t b, size_t e) {
+                uint64_t irr = 0, tot = 0;
+                for (size_t p = b; p < e; ++p) {
+                    memcpy(s + p * PAGE_BYTES, pages[p], PAGE_BYTES);
+                    uint32_t hdr;
+                    memcpy(&hdr, s + p * PAGE_BYTES, 4);
+                    uint32_t nr = hdr & 0xffffu, nv = hdr >> 16;
+                    uint64_t gp = p0 + p;
+                    prow[gp] = nr;
+                    tot += nr;
+                    irr += (nv != nr) ||
+                           (gp + 1 < hc.n_pages ? nr != rows_full : (nr > rows_full || nr == 0));
+                }
+                irregular += irr;
+                total += tot;
+            });
+            RJ_HIP(hipMemcpyAsync(c.owned->as<uint8_t>() + p0 * PAGE_BYTES, s, np * PAGE_BYTES,
+                                  hipMemcpyHostToDevice, lane.stream));
+            RJ_HIP(hipEventRecord(lane.ev[lane.half], lane.stream));
+            lane.used[lane.half] = true;
+            lane.half ^= 1;
+        }
+        c.page_rows_total = total.load();
+        // more rows in the pages than the table declares: the reference throws
+        // std::runtime_error("row_idx") (src/build_table.cpp:334-336)
+        if (c.page_rows_total > t->num_rows) throw_fmt(RJ_ERR_DATA, "row_idx");
+        c.regular = irregular.load() == 0 && c.page_rows_total == t->num_rows;
+        if (!c.regular)  // K1 needs the rows per page on the device
+            RJ_HIP(hipMemcpyAsync(c.page_rows->p, prow, hc.n_pages * 4, hipMemcpyHostToDevice,
+                                  lane.stream));
+    }
+    RJ_HIP(hipStreamSynchronize(lane.stream));
+}
+
+}  // namespace
+
+Table* table_upload(Context* ctx, const rj_input* in, const std::vector<bool>* col_used,
+                    bool borrow_varchar) {
+    std::unique_ptr<Table> t(table_prepare(ctx, in, col_used, borrow_varchar));
+    UploadLane lane(ctx->stream, ctx->staging(2 * CHUNK_PAGES * PAGE_BYTES));
+    table_fill(t.get(), in, lane);
+    return t.release();
+}
+
+// ---------------------------------------------------------------- AsyncUpload --
+struct AsyncUpload::Impl {
+    Context*                            ctx = nullptr;
+    const rj_plan*                      plan = nullptr;
+    std::vector<std::unique_ptr<Table>> tables;
+    std::vector<uint64_t>               order;  // used inputs, in the order the plan walk scans them
+    std::vector<int>                    state;  // 0 = pending, 1 = ready, 2 = failed
+    std::exception_ptr                  error;
+    std::mutex                          m;
+    std::condition_variable             cv;
+    std::atomic<bool>                   cancel{false};
+    std::thread                         th;
+    hipEvent_t                          start = nullptr;
+};
+
+// scans in execution order: children left first (Exec::node)
+static void scan_order(const rj_plan* plan, uint64_t idx, int depth, std::vector<bool>& seen,
+                       std::vector<uint64_t>& order) {
+    if (idx >= plan->n_nodes || depth > 4096) return;  // the plan walk reports it
+    const rj_node& n = plan->nodes[idx];
+    if (n.kind == RJ_NODE_SCAN) {
+        if (n.base_table_id < seen.size() && !seen[n.base_table_id]) {
+            seen[n.base_table_id] = true;
+            order.push_back(n.base_table_id);
+        }
+    } else if (n.kind == RJ_NODE_JOIN) {
+        scan_order(plan, n.left, depth + 1, seen, order);
+        scan_order(plan, n.right, depth + 1, seen, order);
+    }
+}
+
+AsyncUpload::AsyncUpload(Context* ctx, const rj_plan* plan, const std::vector<bool>& used,
+                         const std::vector<std::vector<bool>>& col_used)
+    : im_(new Impl()) {
+    Impl& im = *im_;
+    im.ctx = ctx;
+    im.plan = plan;
+    im.tables.resize(plan->n_inputs);
+    im.state.assign(plan->n_inputs, 0);
+    std::vector<bool> seen(plan->n_inputs, false);
+    scan_order(plan, plan->root, 0, seen, im.order);
+    rj_input none{};
+    for (uint64_t i = 0; i < plan->n_inputs; ++i) {
+        bool up = used[i] && seen[i];
+        im.tables[i].reset(table_prepare(ctx, up ? &plan->inputs[i] : &none,
+                                         up ? &col_used[i] : nullptr, /*borrow_varchar=*/true));
+        if (!up) im.state[i] = 1;
+    }
+    if (im.order.empty()) return;
+    // blocks handed out above may still be read by work queued on the context's stream
+    hipStream_t up = ctx->upload_stream();
+    void*       pinned = ctx->upload_staging(2 * CHUNK_PAGES * PAGE_BYTES);
+    RJ_HIP(hipEventCreateWithFlags(&im.start, hipEventDisableTiming));
+    RJ_HIP(hipEventRecord(im.start, ctx->stream));
+    RJ_HIP(hipStreamWaitEvent(up, im.start, 0));
+    const int device = ctx->device;
+    im.th = std::thread([this, up, pinned, device] {
+        Impl& im = *im_;
+        auto  t0 = std::chrono::steady_clock::now();
+        size_t k = 0;
+        try {
+            RJ_HIP(hipSetDevice(device));
+            UploadLane lane(up, pinned);
+            for (; k < im.order.size() && !im.cancel.load(); ++k) {
+                uint64_t id = im.order[k];
+                table_fill(im.tables[id].get(), &im.plan->inputs[id], lane);
+                {
+                    std::lock_guard<std::mutex> g(im.m);
+                    im.state[id] = 1;
+                }
+                im.cv.notify_all();
+            }
+        } catch (...) {
+            std::lock_guard<std::mutex> g(im.m);
+            im.error = std::current_exception();
+        }
+        {
+            std::lock_guard<std::mutex> g(im.m);
+            for (; k < im.order.size(); ++k)
+                if (im.state[im.order[k]] == 0) im.state[im.order[k]] = 2;
+        }
+        im.cv.notify_all();
+        busy_ms_ = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    });
+}
+
+Table* AsyncUpload::get(uint64_t id) {
+    Impl& im = *im_;
+    if (id >= im.tables.size()) throw_fmt(RJ_ERR_ARG, "scan: bad base_table_id");
+    std::unique_lock<std::mutex> g(im.m);
+    if (im.state[id] == 0) {
+        auto t0 = std::chrono::steady_clock::now();
+        im.cv.wait(g, [&] { return im.state[id] != 0; });
+        wait_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    if (im.state[id] == 2) {
+        if (im.error) std::rethrow_exception(im.error);
+        throw_fmt(RJ_ERR_DEVICE, "upload cancelled");
+    }
+    return im.tables[id].get();
+}
+
+AsyncUpload::~AsyncUpload() {
+    Impl& im = *im_;
+    im.cancel.store(true);
+    if (im.th.joinable()) im.th.join();
+    if (im.start) (void)hipEventDestroy(im.start);
 }
 
 // Result pages -> caller-owned 8 KiB blocks (e.g. `new Page`, so the harness's

@@ -15,7 +15,6 @@
 //                            in parallel slabs.
 #include <algorithm>
 #include <cstring>
-#include <thread>
 
 #include "rj_internal.hpp"
 
@@ -173,45 +172,95 @@ void varchar_gather_encode(const uint8_t* const* pages, uint64_t n_pages,
     // Slabs of 64 K rows are encoded independently (each starts a fresh page — a valid,
     // marginally less dense layout than one greedy pass) so large outputs use all host cores.
     const uint64_t SLAB = 1u << 16;
-    unsigned       hw = std::thread::hardware_concurrency();
     uint64_t       n_slabs = (n + SLAB - 1) / SLAB;
     out_pages.clear();
     n_out_pages = 0;
+    // The lookups are a chain of dependent cache misses into random pages (header -> bitmap
+    // -> offset array -> characters).  Rows are resolved in batches, one link of the chain at
+    // a time with the next link prefetched, so the misses of a batch overlap.
     auto encode = [&](uint64_t b, uint64_t e, std::vector<uint8_t>& out, uint64_t& np) {
         Lookup     lk{pages, n_pages, row_base, {}};
         PageWriter w{out, np};
         out.reserve((e - b) * 24 + PAGE_BYTES);
-        for (uint64_t i = b; i < e; ++i) {
-            const char* p;
-            uint32_t    len;
-            if (lk.get(idx[i], &p, &len))
-                w.add(p, len);
-            else
-                w.add_null();
+        constexpr int  B = 32;
+        const uint8_t* page[B];
+        const uint8_t* bitmap[B];
+        const char*    str[B];
+        uint32_t       at[B], len[B];
+        int            kind[B];  // 0 = NULL, 1 = string in str/len, 2 = long string (slow path)
+        const uint64_t covered = row_base[n_pages];
+        for (uint64_t base = b; base < e; base += B) {
+            const int m = (int)std::min<uint64_t>(B, e - base);
+            for (int k = 0; k < m; ++k) {
+                uint64_t row = idx[base + k];
+                page[k] = nullptr;
+                if (row >= covered) continue;  // rows the pages do not cover are NULL
+                uint64_t pg = (uint64_t)(std::upper_bound(row_base.begin(), row_base.end(), row) -
+                                         row_base.begin()) - 1;
+                page[k] = pages[pg];
+                at[k] = (uint32_t)(row - row_base[pg]);
+                __builtin_prefetch(page[k]);
+            }
+            for (int k = 0; k < m; ++k) {
+                kind[k] = 0;
+                if (!page[k]) continue;
+                uint16_t nr = rd16(page[k]);
+                if (nr == 0xffff) {
+                    kind[k] = 2;
+                    continue;
+                }
+                bitmap[k] = page[k] + PAGE_BYTES - (nr + 7) / 8;
+                __builtin_prefetch(bitmap[k]);
+                __builtin_prefetch(bitmap[k] + (at[k] >> 3));
+                kind[k] = 1;
+            }
+            for (int k = 0; k < m; ++k) {
+                if (kind[k] != 1) continue;
+                if (!((bitmap[k][at[k] >> 3] >> (at[k] & 7)) & 1)) {
+                    kind[k] = 0;
+                    continue;
+                }
+                at[k] = popcount_below(bitmap[k], at[k]);  // index among the non-NULL values
+                __builtin_prefetch(page[k] + 4 + (size_t)at[k] * 2);
+            }
+            for (int k = 0; k < m; ++k) {
+                if (kind[k] != 1) continue;
+                const uint8_t* offs = page[k] + 4;
+                uint16_t       nnn = rd16(page[k] + 2);
+                uint32_t       end = rd16(offs + (size_t)at[k] * 2);
+                uint32_t       beg = at[k] ? rd16(offs + (size_t)(at[k] - 1) * 2) : 0;
+                str[k] = reinterpret_cast<const char*>(page[k]) + 4 + (size_t)nnn * 2 + beg;
+                len[k] = end - beg;
+                __builtin_prefetch(str[k]);
+                __builtin_prefetch(str[k] + len[k]);
+            }
+            for (int k = 0; k < m; ++k) {
+                if (kind[k] == 1) {
+                    w.add(str[k], len[k]);
+                } else if (kind[k] == 2) {
+                    const char* p;
+                    uint32_t    l;
+                    if (lk.get(idx[base + k], &p, &l))
+                        w.add(p, l);
+                    else
+                        w.add_null();
+                } else {
+                    w.add_null();
+                }
+            }
         }
         w.finish();
     };
-    if (n_slabs <= 1 || hw <= 1) {
+    if (n_slabs <= 1) {
         encode(0, n, out_pages, n_out_pages);
         return;
     }
     std::vector<std::vector<uint8_t>> parts(n_slabs);
     std::vector<uint64_t>             counts(n_slabs, 0);
-    unsigned                          nt = (unsigned)std::min<uint64_t>(std::min<unsigned>(hw, 32), n_slabs);
-    std::vector<std::thread>          th;
-    std::vector<std::string>          errs(nt);
-    for (unsigned t = 0; t < nt; ++t)
-        th.emplace_back([&, t] {
-            try {
-                for (uint64_t s = t; s < n_slabs; s += nt)
-                    encode(s * SLAB, std::min(n, (s + 1) * SLAB), parts[s], counts[s]);
-            } catch (const std::exception& e) {
-                errs[t] = e.what();
-            }
-        });
-    for (auto& x : th) x.join();
-    for (auto& e : errs)
-        if (!e.empty()) throw_fmt(RJ_ERR_NOMEM, "VARCHAR encode: %s", e.c_str());
+    parallel_for(n_slabs, 1, [&](size_t b, size_t e) {
+        for (size_t s = b; s < e; ++s)
+            encode(s * SLAB, std::min<uint64_t>(n, (s + 1) * SLAB), parts[s], counts[s]);
+    });
     size_t total = 0;
     for (auto& p : parts) total += p.size();
     out_pages.resize(total);
