@@ -160,6 +160,15 @@ void* Context::staging(size_t bytes) {
     return pinned;
 }
 
+int Context::compute_units() {
+    if (n_cu <= 0) {
+        int v = 0;
+        RJ_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device));
+        n_cu = v > 0 ? v : 256;
+    }
+    return n_cu;
+}
+
 hipStream_t Context::upload_stream() {
     if (!copy_stream) RJ_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
     return copy_stream;

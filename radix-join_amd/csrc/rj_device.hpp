@@ -71,6 +71,7 @@ constexpr int PT_TILE    = PT_THREADS * PT_ITEMS; // 16384 tuples = 64 KiB of LD
                                                   // digit runs per tile = fewer partial HBM lines
 constexpr int PT_MAXF    = 512;                   // max fan-out per pass (9 bits)
 constexpr int PT_MAXBITS = 9;
+constexpr int PT_FINEBITS = 15;                   // fine (two-digit) histogram: 2^15 bins = 128 KiB of LDS
 static_assert(PT_THREADS >= PT_MAXF, "thread d scans digit d");
 static_assert(PT_TILE <= 65536, "ranks are packed into 16 bits");
 static_assert(PT_ITEMS % 4 == 0, "full tiles are loaded as 16-byte vectors");
@@ -84,7 +85,8 @@ struct PassParams {
     uint32_t        shift;      // digit = (word0 >> shift) & (F-1)
     uint32_t        fanout_log2;
     uint32_t        tiles_per_group;
-    uint32_t*       group_hist; // [groups][F]   written by the histogram kernel
+    uint32_t*       group_hist; // [groups][F]   written by the histogram kernel; nullptr = every
+                                //               tile reserves its own ranges (fine-histogram plans)
     uint32_t*       hist;       // [nseg*F]      global bin totals
     uint32_t*       cursor;     // [nseg*F]      write cursors (start = exclusive scan of hist)
 };

@@ -323,6 +323,28 @@ class Exec {
         uint32_t nseg = 1, shift = shift0;
         Words    cur{}, nxt = wa;
         bool     cur_is_a = false;
+        // Two passes whose final partitions fit one LDS histogram: both digits are counted in a
+        // single read of the source, the scatters reserve their ranges tile by tile, and the
+        // second histogram pass (4 B/tuple) disappears.
+        const bool fine = passes == 2 && bits <= (uint32_t)PT_FINEBITS && !external &&
+                          tune("RJ_TUNE_FINE", 1) != 0;
+        BufP       fine_off, fine_cursor, coarse_off, coarse_cursor;
+        if (fine) {
+            const uint32_t NB = 1u << bits, F1 = 1u << pbits[0], F2 = 1u << pbits[1];
+            BufP           fh = ctx->buf((uint64_t)NB * 4);
+            fine_off = ctx->buf(((uint64_t)NB + 1) * 4);
+            fine_cursor = ctx->buf((uint64_t)NB * 4);
+            coarse_off = ctx->buf(((uint64_t)F1 + 1) * 4);
+            coarse_cursor = ctx->buf((uint64_t)F1 * 4);
+            RJ_HIP(hipMemsetAsync(fh->p, 0, (uint64_t)NB * 4, ctx->stream));
+            const uint64_t tiles = (n + PT_TILE - 1) / PT_TILE;
+            launch_fine_hist_src(L, src, KW, shift0, pbits[0], pbits[1],
+                                 (uint32_t)std::min<uint64_t>(tiles, (uint64_t)ctx->compute_units()),
+                                 fh->as<uint32_t>());
+            launch_scan_fine(L, fh->as<uint32_t>(), F1, F2, fine_off->as<uint32_t>(),
+                             fine_cursor->as<uint32_t>(), coarse_off->as<uint32_t>(),
+                             coarse_cursor->as<uint32_t>());
+        }
         for (uint32_t p = 0; p < passes; ++p) {
             const uint32_t F = 1u << pbits[p];
             const uint64_t bins = (uint64_t)nseg * F;
@@ -347,6 +369,21 @@ class Exec {
                                    grp_start->as<uint32_t>());
                 pp.seg_off = seg_off->as<uint32_t>();
                 pp.grp_start = grp_start->as<uint32_t>();
+            }
+            if (fine) {
+                BufP off = p == 0 ? coarse_off : fine_off;
+                pp.cursor = (p == 0 ? coarse_cursor : fine_cursor)->as<uint32_t>();
+                if (p == 0)
+                    launch_pass_scatter_src(L, src, KW, CW, pp, n_groups, nxt);
+                else
+                    launch_pass_scatter_dense(L, cur, P.NW, pp, n_groups, nxt);
+                seg_off = off;
+                nseg = (uint32_t)bins;
+                shift += pbits[p];
+                cur = nxt;
+                cur_is_a = (p % 2 == 0);
+                nxt = cur_is_a ? wb : wa;
+                continue;
             }
             BufP ghist = ctx->buf((uint64_t)std::max<uint32_t>(n_groups, 1) * F * 4);
             BufP hist = ctx->buf(bins * 4);

@@ -184,6 +184,8 @@ struct Context {
                         : (void (*)(void*)) nullptr;
         return L;
     }
+    int   n_cu = 0;
+    int   compute_units();  // CUs of the device (persistent-kernel grids)
     BufP  buf(size_t bytes) { return std::make_shared<Buf>(this, bytes ? bytes : 16); }
     void* staging(size_t bytes);
     void  sync() { RJ_HIP(hipStreamSynchronize(stream)); }

@@ -529,6 +529,69 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_hist(Loader ld, PassParams 
     }
 }
 
+// Two-pass plans whose final partition count fits an LDS histogram (<= 2^PT_FINEBITS bins)
+// count BOTH digits in the one read of the source: bin q = d1 * F2 + d2 is the final
+// partition, its exclusive scan is at once the pass-2 offsets and (every F2-th entry) the
+// pass-1 offsets, and no second histogram pass over the partitioned tuples is needed.
+// Persistent workgroups (one per CU: the histogram takes most of the LDS) stride over the
+// tiles and flush their bins with one global add each.
+template <class Loader>
+__global__ __launch_bounds__(PT_THREADS) void k_fine_hist(Loader ld, uint32_t n, uint32_t shift,
+                                                          uint32_t b1, uint32_t b2,
+                                                          uint32_t* fine) {
+    __shared__ uint32_t s_f[1u << PT_FINEBITS];
+    const uint32_t      NB = 1u << (b1 + b2), m1 = (1u << b1) - 1u, m2 = (1u << b2) - 1u;
+    for (uint32_t d = threadIdx.x; d < NB; d += PT_THREADS) s_f[d] = 0;
+    lds_barrier();
+    const uint32_t tiles = (uint32_t)(((uint64_t)n + PT_TILE - 1) / PT_TILE);
+    for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        uint32_t hk[PT_ITEMS];
+        uint32_t ok = ld.key_tile(t * (uint32_t)PT_TILE, n, hk);
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS; ++j)
+            if ((ok >> j) & 1u) {
+                const uint32_t h = hk[j] >> shift;
+                atomicAdd(&s_f[((h & m1) << b2) | ((h >> b1) & m2)], 1u);
+            }
+    }
+    lds_barrier();
+    for (uint32_t d = threadIdx.x; d < NB; d += PT_THREADS) {
+        uint32_t c = s_f[d];
+        if (c) atomicAdd(&fine[d], c);
+    }
+}
+
+// Exclusive scan of the fine histogram, one workgroup per pass-1 digit: the workgroup sums
+// everything below its F2 bins (coalesced, the whole histogram is 128 KiB of L2), scans its
+// own bins on top, and with that writes the pass-2 offsets/cursors of its segment and the
+// pass-1 offset/cursor of its digit — one launch instead of a serial walk over 2^15 bins.
+__global__ __launch_bounds__(PT_MAXF) void k_scan_fine(const uint32_t* fine, uint32_t F1,
+                                                       uint32_t F2, uint32_t* off2,
+                                                       uint32_t* cursor2, uint32_t* off1,
+                                                       uint32_t* cursor1) {
+    __shared__ uint32_t s_wsum[PT_MAXF / 64];
+    const uint32_t      d1 = blockIdx.x, below = d1 * F2;
+    uint32_t            sum = 0;
+    for (uint32_t i = threadIdx.x; i < below; i += PT_MAXF) sum += fine[i];
+    uint32_t base, tot;
+    (void)block_excl_scan(sum, s_wsum, base);
+    lds_barrier();
+    const uint32_t v = threadIdx.x < F2 ? fine[below + threadIdx.x] : 0u;
+    const uint32_t ex = block_excl_scan(v, s_wsum, tot);
+    if (threadIdx.x < F2) {
+        off2[below + threadIdx.x] = base + ex;
+        cursor2[below + threadIdx.x] = base + ex;
+    }
+    if (threadIdx.x == 0) {
+        off1[d1] = base;
+        cursor1[d1] = base;
+        if (d1 + 1 == F1) {
+            off1[F1] = base + tot;
+            off2[(size_t)F1 * F2] = base + tot;
+        }
+    }
+}
+
 // ================================================================ K4 scatter
 // Scatter half of the radix partition (reference counterpart: the serial
 // scatter src/execute.cpp:175-184).  Per tile of 8192 tuples:
@@ -551,8 +614,11 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassPara
 
     // Thread d owns digit d's write cursor in a REGISTER: the reservation's round trip is
     // not waited for until the first tile has been loaded and ranked.
-    uint32_t run = 0;
-    if (threadIdx.x < F) {
+    // Without group counts (fine-histogram plans) every tile reserves its own ranges instead,
+    // right after ranking; that round trip hides behind the staging of word 0.
+    const bool per_tile = pp.group_hist == nullptr;
+    uint32_t   run = 0;
+    if (!per_tile && threadIdx.x < F) {
         uint32_t c = pp.group_hist[(size_t)blockIdx.x * F + threadIdx.x];
         if (c) run = atomicAdd(&pp.cursor[(size_t)seg * F + threadIdx.x], c);
     }
@@ -578,13 +644,10 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassPara
 
         // PT_THREADS >= PT_MAXF: thread d scans digit d
         uint32_t c = threadIdx.x < F ? s_cnt[threadIdx.x] : 0u;
+        if (per_tile && c) run = atomicAdd(&pp.cursor[(size_t)seg * F + threadIdx.x], c);
         uint32_t total;
         uint32_t ex = block_excl_scan(c, s_wsum, total);
-        if (threadIdx.x < F) {
-            s_base[threadIdx.x] = ex;
-            s_delta[threadIdx.x] = run - ex;  // global index = delta + LDS position
-            run += c;
-        }
+        if (threadIdx.x < F) s_base[threadIdx.x] = ex;
         lds_barrier();
 
         // LDS position of every tuple, computed once for all word arrays
@@ -598,6 +661,10 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassPara
 #pragma unroll
         for (int j = 0; j < PT_ITEMS; ++j)
             if (dr[j] != 0xffffffffu) s_stage[dr[j]] = w[j][0];
+        if (threadIdx.x < F) {
+            s_delta[threadIdx.x] = run - ex;  // global index = delta + LDS position
+            run += c;
+        }
         lds_barrier();
         uint32_t dest[PT_ITEMS];
 #pragma unroll
@@ -1203,6 +1270,25 @@ void launch_pass_hist_src(const Launch& L, const TupleSrc& src, int key_words, c
         SrcLoader<2, 0> ld{src};
         RJ_KLAUNCH(L, "pass1_hist", (k_pass_hist<SrcLoader<2, 0>>), n_groups, PT_THREADS, ld, pp);
     }
+}
+
+void launch_fine_hist_src(const Launch& L, const TupleSrc& src, int key_words, uint32_t shift,
+                          uint32_t b1, uint32_t b2, uint32_t grid, uint32_t* fine) {
+    if (!grid || !src.n_rows) return;
+    if (key_words == 1) {
+        SrcLoader<1, 0> ld{src};
+        RJ_KLAUNCH(L, "pass1_hist", (k_fine_hist<SrcLoader<1, 0>>), grid, PT_THREADS, ld, src.n_rows,
+                   shift, b1, b2, fine);
+    } else {
+        SrcLoader<2, 0> ld{src};
+        RJ_KLAUNCH(L, "pass1_hist", (k_fine_hist<SrcLoader<2, 0>>), grid, PT_THREADS, ld, src.n_rows,
+                   shift, b1, b2, fine);
+    }
+}
+
+void launch_scan_fine(const Launch& L, const uint32_t* fine, uint32_t F1, uint32_t F2,
+                      uint32_t* off2, uint32_t* cursor2, uint32_t* off1, uint32_t* cursor1) {
+    RJ_KLAUNCH(L, "scan_fine", k_scan_fine, F1, PT_MAXF, fine, F1, F2, off2, cursor2, off1, cursor1);
 }
 
 template <int KW, int CW>
