@@ -85,8 +85,6 @@ struct PassParams {
     uint32_t        shift;      // digit = (word0 >> shift) & (F-1)
     uint32_t        fanout_log2;
     uint32_t        tiles_per_group;
-    uint32_t*       group_hist; // [groups][F]   written by the histogram kernel; nullptr = every
-                                //               tile reserves its own ranges (fine-histogram plans)
     uint32_t*       hist;       // [nseg*F]      global bin totals
     uint32_t*       cursor;     // [nseg*F]      write cursors (start = exclusive scan of hist)
 };

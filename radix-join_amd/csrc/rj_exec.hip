@@ -385,12 +385,10 @@ class Exec {
                 nxt = cur_is_a ? wb : wa;
                 continue;
             }
-            BufP ghist = ctx->buf((uint64_t)std::max<uint32_t>(n_groups, 1) * F * 4);
             BufP hist = ctx->buf(bins * 4);
             BufP off = ctx->buf((bins + 1) * 4);
             BufP cursor = ctx->buf(bins * 4);
             RJ_HIP(hipMemsetAsync(hist->p, 0, bins * 4, ctx->stream));
-            pp.group_hist = ghist->as<uint32_t>();
             pp.hist = hist->as<uint32_t>();
             pp.cursor = cursor->as<uint32_t>();
             if (p == 0) {

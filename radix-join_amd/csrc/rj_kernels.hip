@@ -504,8 +504,8 @@ __device__ __forceinline__ bool group_range(const PassParams& pp, uint32_t g, ui
 
 // ============================================================== K2 histogram
 // Counting half of the radix partition (reference counterpart: the serial
-// histogram src/execute.cpp:124-132).  LDS atomics per tuple, one coalesced
-// row of F counters per group to HBM (+ F global adds for the bin totals).
+// histogram src/execute.cpp:124-132).  LDS atomics per tuple, F global adds per group for
+// the bin totals.
 template <class Loader>
 __global__ __launch_bounds__(PT_THREADS) void k_pass_hist(Loader ld, PassParams pp) {
     __shared__ uint32_t s_h[PT_MAXF];
@@ -524,7 +524,6 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_hist(Loader ld, PassParams 
     lds_barrier();
     for (uint32_t d = threadIdx.x; d < F; d += PT_THREADS) {
         uint32_t c = s_h[d];
-        pp.group_hist[(size_t)blockIdx.x * F + d] = c;
         if (c) atomicAdd(&pp.hist[(size_t)seg * F + d], c);
     }
 }
@@ -600,7 +599,8 @@ __global__ __launch_bounds__(PT_MAXF) void k_scan_fine(const uint32_t* fine, uin
 //   3. per word array the tile is written to LDS in digit order, then copied out
 //      so that consecutive lanes write consecutive addresses of one digit's run
 //      (software write-combining: HBM sees contiguous runs, not 4-byte scatters).
-// The group reserved its output ranges up front with one atomic per digit.
+// Every tile reserves its output ranges with one atomic per digit (cursor = start of the
+// digit's partition, from the scanned histogram).
 template <int NW, class Loader>
 __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassParams pp, Words out) {
     __shared__ uint32_t s_stage[PT_TILE];
@@ -614,14 +614,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassPara
 
     // Thread d owns digit d's write cursor in a REGISTER: the reservation's round trip is
     // not waited for until the first tile has been loaded and ranked.
-    // Without group counts (fine-histogram plans) every tile reserves its own ranges instead,
-    // right after ranking; that round trip hides behind the staging of word 0.
-    const bool per_tile = pp.group_hist == nullptr;
-    uint32_t   run = 0;
-    if (!per_tile && threadIdx.x < F) {
-        uint32_t c = pp.group_hist[(size_t)blockIdx.x * F + threadIdx.x];
-        if (c) run = atomicAdd(&pp.cursor[(size_t)seg * F + threadIdx.x], c);
-    }
+    uint32_t run = 0;  // thread d: where digit d's run of the current tile starts in the output
 
     for (uint32_t base = begin; base < end; base += PT_TILE) {
         for (uint32_t d = threadIdx.x; d < F; d += PT_THREADS) s_cnt[d] = 0;
@@ -643,8 +636,10 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassPara
         lds_barrier();
 
         // PT_THREADS >= PT_MAXF: thread d scans digit d
+        // Thread d reserves digit d's range of this tile with one global atomic; its round
+        // trip is not waited for until word 0 has been staged.
         uint32_t c = threadIdx.x < F ? s_cnt[threadIdx.x] : 0u;
-        if (per_tile && c) run = atomicAdd(&pp.cursor[(size_t)seg * F + threadIdx.x], c);
+        if (c) run = atomicAdd(&pp.cursor[(size_t)seg * F + threadIdx.x], c);
         uint32_t total;
         uint32_t ex = block_excl_scan(c, s_wsum, total);
         if (threadIdx.x < F) s_base[threadIdx.x] = ex;
@@ -661,10 +656,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassPara
 #pragma unroll
         for (int j = 0; j < PT_ITEMS; ++j)
             if (dr[j] != 0xffffffffu) s_stage[dr[j]] = w[j][0];
-        if (threadIdx.x < F) {
-            s_delta[threadIdx.x] = run - ex;  // global index = delta + LDS position
-            run += c;
-        }
+        if (threadIdx.x < F) s_delta[threadIdx.x] = run - ex;  // global index = delta + LDS position
         lds_barrier();
         uint32_t dest[PT_ITEMS];
 #pragma unroll

@@ -42,7 +42,6 @@ void launch_pass_hist_src(const Launch& L, const TupleSrc& src, int key_words, c
 // Fine histogram of a two-pass plan (both digits in one read of the source): fine[d1 * F2 + d2],
 // pre-zeroed; `grid` persistent workgroups (one per CU).  launch_scan_fine turns it into the
 // pass-2 offsets/cursors (off2[F1*F2 + 1], cursor2) and the pass-1 ones (off1[F1 + 1], cursor1).
-// Scatters then run with group_hist == nullptr.
 void launch_fine_hist_src(const Launch& L, const TupleSrc& src, int key_words, uint32_t shift,
                           uint32_t b1, uint32_t b2, uint32_t grid, uint32_t* fine);
 void launch_scan_fine(const Launch& L, const uint32_t* fine, uint32_t F1, uint32_t F2,
