@@ -1137,19 +1137,23 @@ __global__ __launch_bounds__(256) void k_finish_streams(FinishStreams fs,
                                                         uint64_t cap_rows) {
     const uint64_t n_rows = *n_rows_dev;
     if (n_rows > cap_rows) return;  // overflow: the host re-runs the probe with larger buffers
-    const uint32_t b = blockIdx.y;
+    // one wave per page: the header and a bitmap of at most 248 bytes
+    const uint32_t b = blockIdx.y, lane = threadIdx.x & 63u;
     const uint32_t rf = fs.rows_full[b];
-    const uint64_t first = (uint64_t)blockIdx.x * rf;
+    const uint64_t pg = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint64_t first = pg * rf;
     if (first >= n_rows) return;
-    uint8_t*       page = fs.pages[b] + (size_t)blockIdx.x * PAGE_BYTES;
+    uint8_t*       page = fs.pages[b] + (size_t)pg * PAGE_BYTES;
     const uint32_t nr = (uint32_t)min((uint64_t)rf, n_rows - first);
     const uint32_t nb = (nr + 7) / 8;
-    if (threadIdx.x == 0) {
-        reinterpret_cast<uint16_t*>(page)[0] = (uint16_t)nr;
-        reinterpret_cast<uint16_t*>(page)[1] = (uint16_t)nr;
-    }
+    if (lane == 0) *reinterpret_cast<uint32_t*>(page) = nr | (nr << 16);  // n_rows, n_nonnull
     uint8_t* bm = page + PAGE_BYTES - nb;
-    for (uint32_t k = threadIdx.x; k < nb; k += blockDim.x) {
+    if (nr == rf && (nr & 31u) == 0 && ((PAGE_BYTES - nb) & 3u) == 0) {
+        // full INT32 page: 248 bytes of ones, dword aligned
+        for (uint32_t k = lane; k < nb / 4; k += 64) reinterpret_cast<uint32_t*>(bm)[k] = 0xffffffffu;
+        return;
+    }
+    for (uint32_t k = lane; k < nb; k += 64) {
         uint32_t bits = nr - k * 8u;
         bm[k] = bits >= 8 ? 0xff : (uint8_t)((1u << bits) - 1u);
     }
@@ -1423,8 +1427,8 @@ void launch_finish_streams(const Launch& L, uint8_t* const* pages, const int* wi
         fs.rows_full[i] = widths[i] == 4 ? ROWS32 : ROWS64;
         max_pages = std::max<uint64_t>(max_pages, (cap_rows + fs.rows_full[i] - 1) / fs.rows_full[i]);
     }
-    RJ_KLAUNCH(L, "finish_pages", k_finish_streams, dim3((uint32_t)max_pages, n), 256, fs, n_rows_dev,
-               cap_rows);
+    RJ_KLAUNCH(L, "finish_pages", k_finish_streams, dim3((uint32_t)((max_pages + 3) / 4), n), 256, fs,
+               n_rows_dev, cap_rows);
 }
 
 void launch_encode_nullable(const Launch& L, const uint8_t* values, const uint8_t* valid,

@@ -2,7 +2,7 @@
 """Condense rocprofv3 CSV output (kernel stats + PMC passes) to the rj:: kernels.
 
 usage: prof_summary.py <gpurun_out/prof dir> <out.md>
-  expects  <dir>/trace/**/_kernel_stats.csv   (--kernel-trace --stats)
+  expects  <dir>/trace/**/_kernel_stats.csv   (--kernel-trace --stats)   or **/*_results.db (rocpd)
            <dir>/fetch/**/_counter_collection.csv (--pmc FETCH_SIZE)   [optional]
            <dir>/write/**/_counter_collection.csv (--pmc WRITE_SIZE)   [optional]
 """
@@ -21,8 +21,23 @@ def short(name):
     return m.group(1) + (m.group(2) or "")
 
 
+def _dbs(d, sub):
+    return glob.glob(os.path.join(d, sub, "**", "*_results.db"), recursive=True)
+
+
 def kernel_stats(d):
     rows = []
+    # rocprofv3's default output is a rocpd SQLite database; CSV only with --output-format csv
+    for f in _dbs(d, "trace"):
+        import sqlite3
+
+        acc = defaultdict(list)
+        for name, dur in sqlite3.connect(f).execute("select name, duration from kernels"):
+            s = short(name)
+            if s:
+                acc[s].append(float(dur))
+        for s, v in acc.items():
+            rows.append((s, len(v), sum(v), sum(v) / len(v), min(v), max(v)))
     for f in glob.glob(os.path.join(d, "trace", "**", "*_kernel_stats.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             s = short(r["Name"])
@@ -33,6 +48,14 @@ def kernel_stats(d):
 
 def pmc(d, sub, counter):
     acc = defaultdict(list)
+    for f in _dbs(d, sub):
+        import sqlite3
+
+        q = "select kernel_name, value from counters_collection where counter_name = ?"
+        for name, val in sqlite3.connect(f).execute(q, (counter,)):
+            s = short(name)
+            if s:
+                acc[s].append(float(val))
     for f in glob.glob(os.path.join(d, sub, "**", "*_counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             s = short(r["Kernel_Name"])
