@@ -6,6 +6,8 @@ deep or bushy, random build side), join keys picked among the children's columns
 type, occasionally of DIFFERENT types — which must give an empty result, reference
 src/execute.cpp:65-71), and random output lists with reordering and duplicates.  Results are
 compared as sorted row multisets."""
+import os
+
 import numpy as np
 import pytest
 
@@ -108,7 +110,11 @@ def random_plan(seed):
     return p
 
 
-@pytest.mark.parametrize("seed", range(200))
+# RJ_FUZZ_SEEDS="first:count" widens the sweep for soak runs (default: seeds 0..199)
+_FIRST, _COUNT = (int(x) for x in os.environ.get("RJ_FUZZ_SEEDS", "0:200").split(":"))
+
+
+@pytest.mark.parametrize("seed", range(_FIRST, _FIRST + _COUNT))
 def test_random_plan(ctx, seed):
     p = random_plan(seed)
     want = _oracle.execute(p)
@@ -117,4 +123,24 @@ def test_random_plan(ctx, seed):
     got = capi.execute(p, ctx)
     assert got.num_rows == want.num_rows
     assert [c.type for c in got.columns] == [c.type for c in want.columns]
+    assert pl.canonical_rows(got) == pl.canonical_rows(want)
+
+
+# The same random plans under forced radix plans: small inputs never reach the multi-pass
+# partitioner on their own.  11 bits = two passes with the fine (two-digit) histogram,
+# 17 bits = two passes above its LDS limit, 20 bits = three passes; nearly all partitions
+# are empty or hold a single tuple.
+@pytest.mark.parametrize("bits", [11, 17, 20])
+@pytest.mark.parametrize("seed", range(_FIRST, _FIRST + min(_COUNT, 40)))
+def test_random_plan_forced_radix(seed, bits):
+    p = random_plan(seed)
+    want = _oracle.execute(p)
+    if want.num_rows > 400_000:
+        pytest.skip("result too large to sort in a unit test")
+    c = capi.Context(radix_bits=bits)
+    try:
+        got = capi.execute(p, c)
+    finally:
+        c.destroy()
+    assert got.num_rows == want.num_rows
     assert pl.canonical_rows(got) == pl.canonical_rows(want)
