@@ -289,6 +289,81 @@ RJ_CASE(error_contract, "errors are std::runtime_error") {
     REQUIRE(threw);
 }
 
+// ---------------------------------------------------------------- large case
+// Not one of the reference's unit cases: 2 M x 3 M PK-FK through the same shim, so that the
+// page marshalling (thousands of individually allocated Pages in, `new Page`s out), the
+// multi-pass partitioner and the VARCHAR materialisation are exercised from C++ as well.
+// R(key INT32 unique, pay INT32 = 7*key+1, name VARCHAR = "s<key>"), S(key INT32 = FK, pay INT32 = row).
+static Column int32_column(const std::vector<int32_t>& v) {
+    Column col(DataType::INT32);
+    const size_t cap = 1984;  // reference include/plan.h:205 for a NULL-free INT32 page
+    for (size_t b = 0; b < v.size(); b += cap) {
+        size_t     n = std::min(cap, v.size() - b);
+        std::byte* p = col.new_page()->data;
+        memset(p, 0, PAGE_SIZE);
+        put16(p, uint16_t(n));
+        put16(p + 2, uint16_t(n));
+        memcpy(p + 4, v.data() + b, n * 4);
+        size_t nb = (n + 7) / 8;
+        memset(p + PAGE_SIZE - nb, 0xff, nb);
+        if (n % 8) *reinterpret_cast<uint8_t*>(p + PAGE_SIZE - 1) = uint8_t((1u << (n % 8)) - 1u);
+    }
+    return col;
+}
+
+RJ_CASE(large_join, "Large PK-FK join with VARCHAR payload") {
+    const uint32_t nR = 2'000'000, nS = 3'000'000;
+    std::vector<int32_t> rk(nR), rp(nR), sk(nS), sp(nS);
+    for (uint32_t i = 0; i < nR; ++i) {
+        rk[i] = int32_t((uint64_t(i) * 2654435761ull + 17) % nR);  // a bijection of [0, nR)
+        rp[i] = rk[i] * 7 + 1;
+    }
+    for (uint32_t j = 0; j < nS; ++j) {
+        sk[j] = int32_t((uint64_t(j) * 40503ull + 5) % nR);
+        sp[j] = int32_t(j);
+    }
+    std::vector<Row> names(nR, Row(1));
+    for (uint32_t i = 0; i < nR; ++i) names[i][0] = "s" + std::to_string(rk[i]);
+    ColumnarTable R, S;
+    R.num_rows = nR;
+    R.columns.push_back(int32_column(rk));
+    R.columns.push_back(int32_column(rp));
+    {
+        ColumnarTable nm = to_columnar(names, {DataType::VARCHAR});
+        R.columns.push_back(std::move(nm.columns[0]));
+    }
+    S.num_rows = nS;
+    S.columns.push_back(int32_column(sk));
+    S.columns.push_back(int32_column(sp));
+
+    Plan p;
+    p.inputs.push_back(std::move(R));
+    p.inputs.push_back(std::move(S));
+    size_t r = p.new_scan_node(0, {{0, DataType::INT32}, {1, DataType::INT32}, {2, DataType::VARCHAR}});
+    size_t s = p.new_scan_node(1, {{0, DataType::INT32}, {1, DataType::INT32}});
+    // output: S.pay, R.name, R.key, R.pay
+    p.root = p.new_join_node(true, r, s, 0, 0,
+                             {{4, DataType::INT32}, {2, DataType::VARCHAR}, {0, DataType::INT32}, {1, DataType::INT32}});
+    void*         ctx = Contest::build_context();
+    ColumnarTable out = Contest::execute(p, ctx);
+    Contest::destroy_context(ctx);
+    REQUIRE(out.num_rows == nS);
+    REQUIRE(out.columns.size() == 4);
+    std::vector<Row> rows = from_columnar(out);
+    std::vector<uint8_t> seen(nS, 0);
+    for (const Row& row : rows) {
+        int32_t            j = std::get<int32_t>(row[0]);
+        const std::string& nm = std::get<std::string>(row[1]);
+        int32_t            k = std::get<int32_t>(row[2]);
+        int32_t            pay = std::get<int32_t>(row[3]);
+        REQUIRE(j >= 0 && uint32_t(j) < nS && !seen[j]);
+        seen[j] = 1;
+        REQUIRE(k == sk[j]);
+        REQUIRE(pay == k * 7 + 1);
+        REQUIRE(nm == "s" + std::to_string(k));
+    }
+}
+
 int main() {
     int failed = 0;
     for (auto& c : cases()) {
