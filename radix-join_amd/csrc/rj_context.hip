@@ -92,24 +92,20 @@ hipEvent_t Profiler::get_event() {
     return e;
 }
 
-// Level 1 brackets only the kernels that move the data (each event pair costs a few µs of
-// GPU idle at the kernel boundary); level 2 brackets every launch.
+// Level 1 times only the kernels that move the data, level 2 every launch.  The events are
+// recorded by the launch itself (start/stop timestamps of the dispatch), not by separate
+// event packets around it.
 static bool hot_kernel(const char* n) {
     return !strncmp(n, "pass", 4) || !strncmp(n, "join_build", 10);
 }
 
-void Profiler::begin(const char* name) {
-    skip_ = !on || (level < 2 && !hot_kernel(name));
-    if (skip_) return;
+bool Profiler::timed(const char* name, hipEvent_t* start, hipEvent_t* stop) {
+    if (!on || (level < 2 && !hot_kernel(name))) return false;
     Rec r{name, get_event(), get_event()};
-    RJ_HIP(hipEventRecord(r.a, stream));
     open_.push_back(r);
-}
-
-void Profiler::end() {
-    if (skip_) return;
-    if (!on || open_.empty()) return;
-    RJ_HIP(hipEventRecord(open_.back().b, stream));
+    *start = r.a;
+    *stop = r.b;
+    return true;
 }
 
 void Profiler::drain() {

@@ -92,8 +92,8 @@ class Profiler {
     bool        on = false;
     int         level = 1;  // 1: hot kernels only, 2: every launch
     hipStream_t stream = nullptr;
-    void        begin(const char* name);
-    void        end();
+    // start/stop events for one launch, or false when this launch is not timed
+    bool        timed(const char* name, hipEvent_t* start, hipEvent_t* stop);
     void        drain();  // synchronises, folds finished records into totals
     void        reset();
     struct Tot {
@@ -111,7 +111,6 @@ class Profiler {
     };
     std::vector<Rec>        open_;
     std::vector<hipEvent_t> spare_;
-    bool                    skip_ = false;
     hipEvent_t              get_event();
 };
 
@@ -178,10 +177,9 @@ struct Context {
         Launch L;
         L.stream = stream;
         L.self = this;
-        L.begin = prof.on ? [](void* s, const char* n) { static_cast<Context*>(s)->prof.begin(n); }
-                          : (void (*)(void*, const char*)) nullptr;
-        L.end = prof.on ? [](void* s) { static_cast<Context*>(s)->prof.end(); }
-                        : (void (*)(void*)) nullptr;
+        L.timed = prof.on ? [](void* s, const char* n, hipEvent_t* a, hipEvent_t* b) {
+            return static_cast<Context*>(s)->prof.timed(n, a, b);
+        } : (bool (*)(void*, const char*, hipEvent_t*, hipEvent_t*)) nullptr;
         return L;
     }
     int   n_cu = 0;

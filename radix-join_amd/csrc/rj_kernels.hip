@@ -14,6 +14,8 @@
 //   K8  page finish/encode  Page headers + validity bitmaps of the result
 //
 // Reference counterparts are cited at each kernel (paths relative to the reference).
+#include <hip/hip_ext.h>
+
 #include "rj_kernels.hpp"
 
 #include <algorithm>
@@ -1213,11 +1215,14 @@ __global__ __launch_bounds__(256) void k_encode_nullable(const uint8_t* values, 
 }
 
 // ================================================================== launchers
-#define RJ_KLAUNCH(L, NAME, KERNEL, GRID, BLOCK, ...)                         \
-    do {                                                                      \
-        if ((L).begin) (L).begin((L).self, NAME);                             \
-        hipLaunchKernelGGL(KERNEL, dim3(GRID), dim3(BLOCK), 0, (L).stream, __VA_ARGS__); \
-        if ((L).end) (L).end((L).self);                                       \
+#define RJ_KLAUNCH(L, NAME, KERNEL, GRID, BLOCK, ...)                                          \
+    do {                                                                                       \
+        hipEvent_t _ev0 = nullptr, _ev1 = nullptr;                                             \
+        if ((L).timed && (L).timed((L).self, NAME, &_ev0, &_ev1))                              \
+            hipExtLaunchKernelGGL(KERNEL, dim3(GRID), dim3(BLOCK), 0, (L).stream, _ev0, _ev1,  \
+                                  0, __VA_ARGS__);                                             \
+        else                                                                                   \
+            hipLaunchKernelGGL(KERNEL, dim3(GRID), dim3(BLOCK), 0, (L).stream, __VA_ARGS__);   \
     } while (0)
 
 void launch_page_headers(const Launch& L, const uint8_t* pages, uint32_t n_pages, uint32_t rows_full,

@@ -7,10 +7,12 @@
 namespace rj {
 
 // Stream + optional per-kernel HIP-event timing.  Implemented in rj_context.hip.
+// timed(): should this launch be timed?  If so it hands out the start/stop events the launch
+// itself records (hipExtLaunchKernelGGL: the timestamps of the dispatch packet — no extra
+// event packets, so no idle gaps at the kernel boundaries).
 struct Launch {
     hipStream_t stream;
-    void (*begin)(void* self, const char* name);
-    void (*end)(void* self);
+    bool (*timed)(void* self, const char* name, hipEvent_t* start, hipEvent_t* stop);
     void* self;
 };
 
