@@ -573,7 +573,15 @@ __global__ __launch_bounds__(PT_MAXF) void k_scan_fine(const uint32_t* fine, uin
     __shared__ uint32_t s_wsum[PT_MAXF / 64];
     const uint32_t      d1 = blockIdx.x, below = d1 * F2;
     uint32_t            sum = 0;
-    for (uint32_t i = threadIdx.x; i < below; i += PT_MAXF) sum += fine[i];
+    if ((F2 & 3u) == 0) {  // 16 bytes per load (hipMalloc'd, so `fine` is 16-byte aligned)
+        const uint4* f4 = reinterpret_cast<const uint4*>(fine);
+        for (uint32_t i = threadIdx.x; i < below / 4; i += PT_MAXF) {
+            const uint4 v = f4[i];
+            sum += v.x + v.y + v.z + v.w;
+        }
+    } else {
+        for (uint32_t i = threadIdx.x; i < below; i += PT_MAXF) sum += fine[i];
+    }
     uint32_t base, tot;
     (void)block_excl_scan(sum, s_wsum, base);
     lds_barrier();
