@@ -1,0 +1,84 @@
+"""Mid-scale differential test: random single- and two-join plans over 0.3-4 M-row tables —
+large enough for the multi-pass partitioner with realistically filled partitions (two passes,
+fine histogram, LDS tables at their working load), small enough for the oracle to finish in a
+couple of seconds each.  Duplicate build keys, NULL keys, hot probe keys, INT32/INT64/FP64 keys
+and payloads, nullable payloads.  Compared by order-independent digest of the result rows."""
+import numpy as np
+import pytest
+
+import _oracle
+from pyrj import capi
+from pyrj import plan as pl
+
+pytestmark = pytest.mark.gpu
+
+NP_OF = {pl.INT32: np.int32, pl.INT64: np.int64, pl.FP64: np.float64}
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.build_context()
+    yield c
+    capi.destroy_context(c)
+
+
+def keys(rng, n, domain, dt, hot=0.0):
+    k = rng.integers(0, domain, n)
+    if hot:  # one key owns a fraction `hot` of the rows (heavy-task path on the probe side)
+        k[rng.random(n) < hot] = domain // 3
+    if dt == pl.FP64:
+        return k.astype(np.float64) * 0.5 - 1000.0
+    if dt == pl.INT64:
+        return k.astype(np.int64) * 4_000_000_007 - 12345  # needs the high word
+    return k.astype(np.int32) - 7
+
+
+def column(rng, n, dt, null_frac):
+    if dt == pl.FP64:
+        v = rng.standard_normal(n)
+    elif dt == pl.INT64:
+        v = rng.integers(-(2**62), 2**62, n)
+    else:
+        v = rng.integers(-(2**31), 2**31 - 1, n)
+    v = v.astype(NP_OF[dt])
+    if null_frac:
+        return (dt, v, rng.random(n) >= null_frac)
+    return (dt, v)
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_midscale_random_join(ctx, seed):
+    rng = np.random.default_rng(1000 + seed)
+    kt = [pl.INT32, pl.INT32, pl.INT64, pl.FP64][seed % 4]
+    nb = int(rng.integers(300_000, 3_000_000))
+    npr = int(rng.integers(500_000, 4_000_000))
+    # average build multiplicity between 1 (domain 2x) and 2 (domain 0.5x): output <= ~2 |probe|
+    domain = int(nb * rng.uniform(0.5, 2.0))
+    bk = keys(rng, nb, domain, kt)
+    pk = keys(rng, npr, domain, kt, hot=0.1 if seed % 3 == 0 else 0.0)
+    null_b = 0.05 if seed % 2 else 0.0
+    null_p = 0.08 if seed % 4 == 1 else 0.0
+    bkey = (kt, bk, rng.random(nb) >= null_b) if null_b else (kt, bk)
+    pkey = (kt, pk, rng.random(npr) >= null_p) if null_p else (kt, pk)
+    bcols = [bkey] + [column(rng, nb, int(rng.choice([pl.INT32, pl.INT64, pl.FP64])), 0.1 if seed % 5 == 0 else 0.0)
+                      for _ in range(1 + seed % 2)]
+    pcols = [pkey, column(rng, npr, int(rng.choice([pl.INT32, pl.INT64])), 0.0)]
+    bt, pt = pl.make_table(bcols), pl.make_table(pcols)
+    p = pl.Plan()
+    b = p.new_scan_node(0, [(i, c[0]) for i, c in enumerate(bcols)])
+    s = p.new_scan_node(1, [(i, c[0]) for i, c in enumerate(pcols)])
+    both = [c[0] for c in bcols] + [c[0] for c in pcols]
+    build_left = bool(seed % 2 == 0)
+    if build_left:
+        j = p.new_join_node(True, b, s, 0, 0, [(i, t) for i, t in enumerate(both)])
+    else:  # probe on the left, build on the right (the shape of every JOB hash join)
+        both = [c[0] for c in pcols] + [c[0] for c in bcols]
+        j = p.new_join_node(False, s, b, 0, 0, [(i, t) for i, t in enumerate(both)])
+    p.new_input(bt)
+    p.new_input(pt)
+    p.root = j
+    want = _oracle.execute(p)
+    got = capi.execute(p, ctx)
+    assert got.num_rows == want.num_rows
+    assert want.num_rows > 0
+    assert pl.table_digest(got) == pl.table_digest(want)
