@@ -370,36 +370,29 @@ class Exec {
                 pp.seg_off = seg_off->as<uint32_t>();
                 pp.grp_start = grp_start->as<uint32_t>();
             }
-            if (fine) {
-                BufP off = p == 0 ? coarse_off : fine_off;
-                pp.cursor = (p == 0 ? coarse_cursor : fine_cursor)->as<uint32_t>();
-                if (p == 0)
-                    launch_pass_scatter_src(L, src, KW, CW, pp, n_groups, nxt);
-                else
-                    launch_pass_scatter_dense(L, cur, P.NW, pp, n_groups, nxt);
-                seg_off = off;
-                nseg = (uint32_t)bins;
-                shift += pbits[p];
-                cur = nxt;
-                cur_is_a = (p % 2 == 0);
-                nxt = cur_is_a ? wb : wa;
-                continue;
-            }
-            BufP hist = ctx->buf(bins * 4);
-            BufP off = ctx->buf((bins + 1) * 4);
-            BufP cursor = ctx->buf(bins * 4);
-            RJ_HIP(hipMemsetAsync(hist->p, 0, bins * 4, ctx->stream));
-            pp.hist = hist->as<uint32_t>();
-            pp.cursor = cursor->as<uint32_t>();
-            if (p == 0) {
-                launch_pass_hist_src(L, src, KW, pp, n_groups);
-                launch_scan_segments(L, pp.hist, nullptr, 1, F, off->as<uint32_t>(), pp.cursor);
-                launch_pass_scatter_src(L, src, KW, CW, pp, n_groups, nxt);
+            BufP off, hist, cursor;  // this pass' partition offsets, bin totals, write cursors
+            if (fine) {  // offsets and cursors of both passes came out of the fine histogram
+                off = p == 0 ? coarse_off : fine_off;
+                cursor = p == 0 ? coarse_cursor : fine_cursor;
+                pp.cursor = cursor->as<uint32_t>();
             } else {
-                launch_pass_hist_dense(L, cur, pp, n_groups);
-                launch_scan_segments(L, pp.hist, pp.seg_off, nseg, F, off->as<uint32_t>(), pp.cursor);
-                launch_pass_scatter_dense(L, cur, P.NW, pp, n_groups, nxt);
+                hist = ctx->buf(bins * 4);
+                off = ctx->buf((bins + 1) * 4);
+                cursor = ctx->buf(bins * 4);
+                RJ_HIP(hipMemsetAsync(hist->p, 0, bins * 4, ctx->stream));
+                pp.hist = hist->as<uint32_t>();
+                pp.cursor = cursor->as<uint32_t>();
+                if (p == 0)
+                    launch_pass_hist_src(L, src, KW, pp, n_groups);
+                else
+                    launch_pass_hist_dense(L, cur, pp, n_groups);
+                launch_scan_segments(L, pp.hist, p == 0 ? nullptr : pp.seg_off, nseg, F,
+                                     off->as<uint32_t>(), pp.cursor);
             }
+            if (p == 0)
+                launch_pass_scatter_src(L, src, KW, CW, pp, n_groups, nxt);
+            else
+                launch_pass_scatter_dense(L, cur, P.NW, pp, n_groups, nxt);
             seg_off = off;
             nseg = (uint32_t)bins;
             shift += pbits[p];
