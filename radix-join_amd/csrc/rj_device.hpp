@@ -46,7 +46,8 @@ struct TupleSrc {
     int32_t  prehashed;  // key column already holds hashed keys (sharded stage B)
 };
 
-// Partitioned tuples are SoA arrays of 32-bit words:
+// Partitioned tuples are SoA arrays of 32-bit words (or, for one key word + one carry word in
+// fine-histogram plans, ONE array of 8-byte {word 0, carry} pairs — "packed"):
 //   word 0            = hashed key (low 32 bits); radix digits and slot bits come from it
 //   word 1 (KW == 2)  = high 32 bits of the 64-bit hashed key
 //   following words   = carry (0, 1 or 2 words)
@@ -148,6 +149,7 @@ struct JoinParams {
     const uint32_t* heavy_tasks; // [n][3] = {partition, s_begin, s_end}
     const uint32_t* n_heavy;
     int32_t         heavy_pass;  // 0: one workgroup per partition; 1: heavy task list
+    int32_t         packR, packS; // R.w[0] / S.w[0] is an array of {hashed key, carry} pairs
     int32_t         pad;
     unsigned long long* diag;    // phase cycle counters (RJ_DIAG=1 only), else nullptr
 };

@@ -45,6 +45,7 @@ struct Parted {
     BufP     off;  // u32[NP+1]
     uint32_t NP = 0;
     std::vector<uint32_t> pbits;  // radix bits of each pass
+    bool     packed = false;      // w[0] = {hashed key, carry} pairs, no w[1]
 };
 
 struct JoinSpec {
@@ -305,17 +306,25 @@ class Exec {
             }
         }
 
+        // Two passes whose final partitions fit one LDS histogram: both digits are counted in a
+        // single read of the source, the scatters reserve their ranges tile by tile, and the
+        // second histogram pass (4 B/tuple) disappears.
+        const bool fine = passes == 2 && bits <= (uint32_t)PT_FINEBITS && !external &&
+                          tune("RJ_TUNE_FINE", 1) != 0;
+        // ... and with nothing left that reads keys alone, key + one carry word travel as pairs
+        P.packed = fine && KW == 1 && CW == 1 && tune("RJ_TUNE_PACK", 1) != 0;
         BufP  A[MAX_WORDS], B[MAX_WORDS];
         Words wa{}, wb{};
-        for (int a = 0; a < P.NW; ++a) {
+        for (int a = 0; a < (P.packed ? 1 : P.NW); ++a) {
+            const uint64_t wbytes = P.packed ? 8 : 4;
             if (external) {
                 wa.w[a] = external->w[a];
                 continue;
             }
-            A[a] = ctx->buf(n * 4);
+            A[a] = ctx->buf(n * wbytes);
             wa.w[a] = A[a]->as<uint32_t>();
             if (passes > 1) {
-                B[a] = ctx->buf(n * 4);
+                B[a] = ctx->buf(n * wbytes);
                 wb.w[a] = B[a]->as<uint32_t>();
             }
         }
@@ -323,11 +332,6 @@ class Exec {
         uint32_t nseg = 1, shift = shift0;
         Words    cur{}, nxt = wa;
         bool     cur_is_a = false;
-        // Two passes whose final partitions fit one LDS histogram: both digits are counted in a
-        // single read of the source, the scatters reserve their ranges tile by tile, and the
-        // second histogram pass (4 B/tuple) disappears.
-        const bool fine = passes == 2 && bits <= (uint32_t)PT_FINEBITS && !external &&
-                          tune("RJ_TUNE_FINE", 1) != 0;
         BufP       fine_off, fine_cursor, coarse_off, coarse_cursor;
         if (fine) {
             const uint32_t NB = 1u << bits, F1 = 1u << pbits[0], F2 = 1u << pbits[1];
@@ -389,10 +393,16 @@ class Exec {
                 launch_scan_segments(L, pp.hist, p == 0 ? nullptr : pp.seg_off, nseg, F,
                                      off->as<uint32_t>(), pp.cursor);
             }
-            if (p == 0)
+            if (P.packed) {
+                if (p == 0)
+                    launch_pass_scatter_src_packed(L, src, pp, n_groups, nxt.w[0]);
+                else
+                    launch_pass_scatter_packed(L, cur.w[0], pp, n_groups, nxt.w[0]);
+            } else if (p == 0) {
                 launch_pass_scatter_src(L, src, KW, CW, pp, n_groups, nxt);
-            else
+            } else {
                 launch_pass_scatter_dense(L, cur, P.NW, pp, n_groups, nxt);
+            }
             seg_off = off;
             nseg = (uint32_t)bins;
             shift += pbits[p];
@@ -583,6 +593,8 @@ class Exec {
             JoinParams jp{};
             jp.R = PB.w;
             jp.S = PP.w;
+            jp.packR = PB.packed ? 1 : 0;
+            jp.packS = PP.packed ? 1 : 0;
             jp.offR = PB.off->as<uint32_t>();
             jp.offS = PP.off->as<uint32_t>();
             jp.NP = PB.NP;

@@ -316,6 +316,38 @@ struct DenseLoader {
     }
 };
 
+// Partitioned tuples of ONE key word + ONE carry word can also be kept packed: an array of
+// 8-byte {hashed key, carry} pairs instead of two word arrays (see k_pass_scatter_packed).
+struct PackedLoader {
+    const uint2* in;
+    template <int NW>
+    __device__ __forceinline__ uint32_t load_tile(uint32_t base, uint32_t end,
+                                                  uint32_t (&w)[PT_ITEMS][NW]) const {
+        static_assert(NW == 2, "packed tuples are key + one carry word");
+        if (base + PT_TILE <= end) {  // two consecutive tuples per 16-byte load
+#pragma unroll
+            for (int v = 0; v < PT_ITEMS / 2; ++v) {
+                u32x4a x = *reinterpret_cast<const u32x4a*>(in + base + (v * PT_THREADS + threadIdx.x) * 2);
+                w[2 * v][0] = x[0];
+                w[2 * v][1] = x[1];
+                w[2 * v + 1][0] = x[2];
+                w[2 * v + 1][1] = x[3];
+            }
+            return (1u << PT_ITEMS) - 1u;
+        }
+        uint32_t ok = 0;
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS; ++j) {
+            uint32_t i = base + j * PT_THREADS + threadIdx.x;
+            uint2    t = in[min(i, end - 1u)];
+            w[j][0] = t.x;
+            w[j][1] = t.y;
+            ok |= (uint32_t)(i < end) << j;
+        }
+        return ok;
+    }
+};
+
 // byte offset of row `row` in a 4-byte / 8-byte column (regular page images or dense)
 __device__ __forceinline__ uint64_t col_off32(bool paged, uint32_t row) {
     uint32_t p = row / ROWS32, i = row - p * ROWS32;
@@ -697,6 +729,68 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassPara
     }
 }
 
+// Packed variant for {hashed key, one carry word} tuples (the BASELINE shape): the tile is
+// staged as 8-byte pairs (128 KiB of LDS — the workgroup owns the CU anyway) and copied out
+// with one 8-byte store per tuple into ONE output array.  Against two word arrays this
+// halves the number of output streams and doubles the bytes per contiguous run (a run of 64
+// tuples is 512 contiguous bytes instead of two runs of 256), which is what the scatter's
+// rate follows; it also needs one staging round and two barriers less per tile.
+template <class Loader>
+__global__ __launch_bounds__(PT_THREADS) void k_pass_scatter_packed(Loader ld, PassParams pp, uint2* out) {
+    __shared__ uint2    s_stage[PT_TILE];
+    __shared__ uint32_t s_cnt[PT_MAXF];
+    __shared__ uint32_t s_base[PT_MAXF];
+    __shared__ uint32_t s_delta[PT_MAXF];
+    __shared__ uint32_t s_wsum[PT_THREADS / 64];
+    uint32_t            seg, begin, end;
+    if (!group_range(pp, blockIdx.x, seg, begin, end)) return;
+    const uint32_t F = 1u << pp.fanout_log2, mask = F - 1u;
+
+    uint32_t run = 0;  // thread d: where digit d's run of the current tile starts in the output
+    for (uint32_t base = begin; base < end; base += PT_TILE) {
+        for (uint32_t d = threadIdx.x; d < F; d += PT_THREADS) s_cnt[d] = 0;
+        lds_barrier();
+
+        uint32_t       w[PT_ITEMS][2];
+        uint32_t       dr[PT_ITEMS];  // digit << 16 | rank, 0xffffffff = no tuple
+        const uint32_t ok = ld.template load_tile<2>(base, end, w);
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS; ++j) {
+            dr[j] = 0xffffffffu;
+            if ((ok >> j) & 1u) {
+                uint32_t d = (w[j][0] >> pp.shift) & mask;
+                uint32_t r = atomicAdd(&s_cnt[d], 1u);
+                dr[j] = (d << 16) | r;
+            }
+        }
+        lds_barrier();
+
+        uint32_t c = threadIdx.x < F ? s_cnt[threadIdx.x] : 0u;
+        if (c) run = atomicAdd(&pp.cursor[(size_t)seg * F + threadIdx.x], c);
+        uint32_t total;
+        uint32_t ex = block_excl_scan(c, s_wsum, total);
+        if (threadIdx.x < F) s_base[threadIdx.x] = ex;
+        lds_barrier();
+
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS; ++j)
+            if (dr[j] != 0xffffffffu)
+                s_stage[s_base[dr[j] >> 16] + (dr[j] & 0xffffu)] = make_uint2(w[j][0], w[j][1]);
+        if (threadIdx.x < F) s_delta[threadIdx.x] = run - ex;  // global index = delta + LDS position
+        lds_barrier();
+
+#pragma unroll
+        for (int k = 0; k < PT_ITEMS; ++k) {
+            const uint32_t i = k * PT_THREADS + threadIdx.x;
+            if (i < total) {
+                const uint2 v = s_stage[i];
+                out[s_delta[(v.x >> pp.shift) & mask] + i] = v;
+            }
+        }
+        // no barrier: the next tile passes two barriers before it overwrites s_stage / s_delta
+    }
+}
+
 // ============================================================= heavy task list
 // Probe partitions above JN_HEAVY tuples are cut into tasks so that a skewed
 // (Zipf) probe side does not serialise on one workgroup; each task rebuilds the
@@ -753,7 +847,8 @@ enum { OM_GENERIC = 0, OM_PAGED32 = 1, OM_DENSE32 = 2 };
         }                                                                       \
     } while (0)
 
-template <int KW, int CWR, int CWS, int OM>
+// PK: bit 0 = the build side, bit 1 = the probe side is a packed {hashed key, carry} array
+template <int KW, int CWR, int CWS, int OM, int PK>
 __global__ __launch_bounds__(JN_THREADS, jn_min_waves(KW + (CWR == 2 ? 1 : CWR))) void k_join(JoinParams jp) {
     // A two-word build carry is NOT kept in the LDS table: the table then stores the build
     // tuple's position instead and the carry words are fetched from the partitioned build
@@ -810,8 +905,41 @@ __global__ __launch_bounds__(JN_THREADS, jn_min_waves(KW + (CWR == 2 ? 1 : CWR))
     // tuples per 16-byte load
     uint32_t rw[JN_RPT][RW];
     uint32_t sw[JN_SPT][SW];
+    // item j of a thread holds element item_index(j): four consecutive tuples per 16-byte load
+    // of a word array, two consecutive {key, carry} pairs per load of a packed array
+    auto item_index = [&](int j, bool packed) -> uint32_t {
+        return packed ? ((j / 2) * JN_THREADS + threadIdx.x) * 2 + (j % 2)
+                      : ((j / 4) * JN_THREADS + threadIdx.x) * 4 + (j % 4);
+    };
+    constexpr bool packR = (PK & 1) != 0, packS = (PK & 2) != 0;
+    static_assert(!packR || (KW == 1 && CWR == 1), "packed build side: key + one carry word");
+    static_assert(!packS || (KW == 1 && CWS == 1), "packed probe side: key + one carry word");
     auto load_build = [&](uint32_t rc, uint32_t rn) {
         constexpr int LW = IND ? KW : RW;  // words actually read from the build arrays
+        if constexpr (packR) {
+            {
+                const uint2* rp = reinterpret_cast<const uint2*>(jp.R.w[0]) + rc;
+#pragma unroll
+                for (int v = 0; v < JN_RPT / 2; ++v) {
+                    const uint32_t i0 = (v * JN_THREADS + threadIdx.x) * 2;
+                    if (i0 + 1 < rn) {
+                        u32x4a x = *reinterpret_cast<const u32x4a*>(rp + i0);
+                        rw[2 * v][0] = x[0];
+                        rw[2 * v][1] = x[1];
+                        rw[2 * v + 1][0] = x[2];
+                        rw[2 * v + 1][1] = x[3];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            uint2 t = i0 + e < rn ? rp[i0 + e] : make_uint2(0u, 0u);
+                            rw[2 * v + e][0] = t.x;
+                            rw[2 * v + e][1] = t.y;
+                        }
+                    }
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int v = 0; v < JN_RPT / 4; ++v) {
             const uint32_t i0 = (v * JN_THREADS + threadIdx.x) * 4;
@@ -836,6 +964,30 @@ __global__ __launch_bounds__(JN_THREADS, jn_min_waves(KW + (CWR == 2 ? 1 : CWR))
         }
     };
     auto load_probe = [&](uint32_t sc, uint32_t sn) {
+        if constexpr (packS) {
+            {
+                const uint2* sp = reinterpret_cast<const uint2*>(jp.S.w[0]) + sc;
+#pragma unroll
+                for (int v = 0; v < JN_SPT / 2; ++v) {
+                    const uint32_t i0 = (v * JN_THREADS + threadIdx.x) * 2;
+                    if (i0 + 1 < sn) {
+                        u32x4a x = *reinterpret_cast<const u32x4a*>(sp + i0);
+                        sw[2 * v][0] = x[0];
+                        sw[2 * v][1] = x[1];
+                        sw[2 * v + 1][0] = x[2];
+                        sw[2 * v + 1][1] = x[3];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            uint2 t = i0 + e < sn ? sp[i0 + e] : make_uint2(0u, 0u);
+                            sw[2 * v + e][0] = t.x;
+                            sw[2 * v + e][1] = t.y;
+                        }
+                    }
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int v = 0; v < JN_SPT / 4; ++v) {
             const uint32_t i0 = (v * JN_THREADS + threadIdx.x) * 4;
@@ -925,7 +1077,7 @@ __global__ __launch_bounds__(JN_THREADS, jn_min_waves(KW + (CWR == 2 ? 1 : CWR))
             // ---- build
 #pragma unroll
             for (int j = 0; j < JN_RPT; ++j) {
-                uint32_t i = ((j / 4) * JN_THREADS + threadIdx.x) * 4 + (j % 4);
+                uint32_t i = item_index(j, packR);
                 if (i < rn) {
                     uint32_t b = (rw[j][0] >> jp.radix_bits) & BMASK;
                     while (true) {
@@ -958,7 +1110,7 @@ __global__ __launch_bounds__(JN_THREADS, jn_min_waves(KW + (CWR == 2 ? 1 : CWR))
                 // count matches, remember the first matching slot
 #pragma unroll
                 for (int j = 0; j < JN_SPT; ++j) {
-                    uint32_t i = ((j / 4) * JN_THREADS + threadIdx.x) * 4 + (j % 4);
+                    uint32_t i = item_index(j, packS);
                     m[j] = 0;
                     f[j] = 0;
                     if (i < sn) {
@@ -1354,14 +1506,30 @@ void launch_pass_scatter_dense(const Launch& L, const Words& in, int n_words, co
     }
 }
 
+void launch_pass_scatter_src_packed(const Launch& L, const TupleSrc& src, const PassParams& pp,
+                                    uint32_t n_groups, uint32_t* out_pairs) {
+    if (!n_groups) return;
+    SrcLoader<1, 1> ld{src};
+    RJ_KLAUNCH(L, "pass1_scatter", (k_pass_scatter_packed<SrcLoader<1, 1>>), n_groups, PT_THREADS, ld,
+               pp, reinterpret_cast<uint2*>(out_pairs));
+}
+
+void launch_pass_scatter_packed(const Launch& L, const uint32_t* in_pairs, const PassParams& pp,
+                                uint32_t n_groups, uint32_t* out_pairs) {
+    if (!n_groups) return;
+    PackedLoader ld{reinterpret_cast<const uint2*>(in_pairs)};
+    RJ_KLAUNCH(L, "pass2_scatter", (k_pass_scatter_packed<PackedLoader>), n_groups, PT_THREADS, ld, pp,
+               reinterpret_cast<uint2*>(out_pairs));
+}
+
 void launch_heavy_tasks(const Launch& L, const uint32_t* offR, const uint32_t* offS, uint32_t NP,
                         uint32_t* tasks, uint32_t* n_heavy, uint32_t max_tasks) {
     RJ_KLAUNCH(L, "heavy_tasks", k_heavy_tasks, (NP + 255) / 256, 256, offR, offS, NP, tasks,
                n_heavy, max_tasks);
 }
 
-template <int KW, int CWR, int CWS>
-static void join_t(const Launch& L, const JoinParams& jp, uint32_t grid) {
+template <int KW, int CWR, int CWS, int PK>
+static void join_pk(const Launch& L, const JoinParams& jp, uint32_t grid) {
     const char* name = jp.heavy_pass ? "join_heavy" : "join_build_probe";
     // pick the straight-line emit variant when the stream layout allows it
     int om = OM_GENERIC;
@@ -1375,15 +1543,32 @@ static void join_t(const Launch& L, const JoinParams& jp, uint32_t grid) {
     }
     if constexpr (KW == 1 && CWR <= 1 && CWS <= 1) {
         if (om == OM_PAGED32) {
-            RJ_KLAUNCH(L, name, (k_join<KW, CWR, CWS, OM_PAGED32>), grid, JN_THREADS, jp);
+            RJ_KLAUNCH(L, name, (k_join<KW, CWR, CWS, OM_PAGED32, PK>), grid, JN_THREADS, jp);
             return;
         }
         if (om == OM_DENSE32) {
-            RJ_KLAUNCH(L, name, (k_join<KW, CWR, CWS, OM_DENSE32>), grid, JN_THREADS, jp);
+            RJ_KLAUNCH(L, name, (k_join<KW, CWR, CWS, OM_DENSE32, PK>), grid, JN_THREADS, jp);
             return;
         }
     }
-    RJ_KLAUNCH(L, name, (k_join<KW, CWR, CWS, OM_GENERIC>), grid, JN_THREADS, jp);
+    RJ_KLAUNCH(L, name, (k_join<KW, CWR, CWS, OM_GENERIC, PK>), grid, JN_THREADS, jp);
+}
+
+// the packed variants exist only for the shapes that can be packed
+template <int KW, int CWR, int CWS>
+static void join_t(const Launch& L, const JoinParams& jp, uint32_t grid) {
+    constexpr int CAN = (KW == 1 && CWR == 1 ? 1 : 0) | (KW == 1 && CWS == 1 ? 2 : 0);
+    const int     pk = (jp.packR ? 1 : 0) | (jp.packS ? 2 : 0);
+    if constexpr (CAN == 3) {
+        if (pk == 3) return join_pk<KW, CWR, CWS, 3>(L, jp, grid);
+        if (pk == 1) return join_pk<KW, CWR, CWS, 1>(L, jp, grid);
+        if (pk == 2) return join_pk<KW, CWR, CWS, 2>(L, jp, grid);
+    } else if constexpr (CAN == 1) {
+        if (pk == 1) return join_pk<KW, CWR, CWS, 1>(L, jp, grid);
+    } else if constexpr (CAN == 2) {
+        if (pk == 2) return join_pk<KW, CWR, CWS, 2>(L, jp, grid);
+    }
+    join_pk<KW, CWR, CWS, 0>(L, jp, grid);
 }
 
 void launch_join(const Launch& L, int key_words, int cw_build, int cw_probe, const JoinParams& jp,

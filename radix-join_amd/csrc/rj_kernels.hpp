@@ -56,6 +56,12 @@ void launch_pass_hist_dense(const Launch& L, const Words& in, const PassParams& 
 void launch_pass_scatter_dense(const Launch& L, const Words& in, int n_words, const PassParams& pp,
                                uint32_t n_groups, const Words& out);
 
+// Packed layout ({hashed key, carry} pairs in one array) for one key word + one carry word.
+void launch_pass_scatter_src_packed(const Launch& L, const TupleSrc& src, const PassParams& pp,
+                                    uint32_t n_groups, uint32_t* out_pairs);
+void launch_pass_scatter_packed(const Launch& L, const uint32_t* in_pairs, const PassParams& pp,
+                                uint32_t n_groups, uint32_t* out_pairs);
+
 // ---- build + probe (replaces reference src/execute.cpp:196-249)
 void launch_heavy_tasks(const Launch& L, const uint32_t* offR, const uint32_t* offS, uint32_t NP,
                         uint32_t* tasks, uint32_t* n_heavy, uint32_t max_tasks);
