@@ -311,8 +311,11 @@ class Exec {
         // second histogram pass (4 B/tuple) disappears.
         const bool fine = passes == 2 && bits <= (uint32_t)PT_FINEBITS && !external &&
                           tune("RJ_TUNE_FINE", 1) != 0;
-        // ... and with nothing left that reads keys alone, key + one carry word travel as pairs
-        P.packed = fine && KW == 1 && CW == 1 && tune("RJ_TUNE_PACK", 1) != 0;
+        // key + one carry word travel as 8-byte pairs in one array (half the streams, twice the
+        // bytes per run); RJ_TUNE_PACK: 0 = never, 1 = every plan, 2 = fine-histogram plans only
+        // (a later pass' plain histogram reads 8 instead of 4 bytes per tuple from pairs)
+        const int pack_mode = tune("RJ_TUNE_PACK", 1);
+        P.packed = !external && KW == 1 && CW == 1 && (pack_mode == 1 || (pack_mode == 2 && fine));
         BufP  A[MAX_WORDS], B[MAX_WORDS];
         Words wa{}, wb{};
         for (int a = 0; a < (P.packed ? 1 : P.NW); ++a) {
@@ -388,6 +391,8 @@ class Exec {
                 pp.cursor = cursor->as<uint32_t>();
                 if (p == 0)
                     launch_pass_hist_src(L, src, KW, pp, n_groups);
+                else if (P.packed)
+                    launch_pass_hist_packed(L, cur.w[0], pp, n_groups);
                 else
                     launch_pass_hist_dense(L, cur, pp, n_groups);
                 launch_scan_segments(L, pp.hist, p == 0 ? nullptr : pp.seg_off, nseg, F,

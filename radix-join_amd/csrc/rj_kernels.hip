@@ -320,6 +320,27 @@ struct DenseLoader {
 // 8-byte {hashed key, carry} pairs instead of two word arrays (see k_pass_scatter_packed).
 struct PackedLoader {
     const uint2* in;
+    // keys only (histogram of a later pass): every second word of the pairs
+    __device__ __forceinline__ uint32_t key_tile(uint32_t base, uint32_t end,
+                                                 uint32_t (&hk)[PT_ITEMS]) const {
+        if (base + PT_TILE <= end) {
+#pragma unroll
+            for (int v = 0; v < PT_ITEMS / 2; ++v) {
+                u32x4a x = *reinterpret_cast<const u32x4a*>(in + base + (v * PT_THREADS + threadIdx.x) * 2);
+                hk[2 * v] = x[0];
+                hk[2 * v + 1] = x[2];
+            }
+            return (1u << PT_ITEMS) - 1u;
+        }
+        uint32_t ok = 0;
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS; ++j) {
+            uint32_t i = base + j * PT_THREADS + threadIdx.x;
+            hk[j] = in[min(i, end - 1u)].x;
+            ok |= (uint32_t)(i < end) << j;
+        }
+        return ok;
+    }
     template <int NW>
     __device__ __forceinline__ uint32_t load_tile(uint32_t base, uint32_t end,
                                                   uint32_t (&w)[PT_ITEMS][NW]) const {
@@ -1504,6 +1525,13 @@ void launch_pass_scatter_dense(const Launch& L, const Words& in, int n_words, co
         break;
     default: break;
     }
+}
+
+void launch_pass_hist_packed(const Launch& L, const uint32_t* in_pairs, const PassParams& pp,
+                             uint32_t n_groups) {
+    if (!n_groups) return;
+    PackedLoader ld{reinterpret_cast<const uint2*>(in_pairs)};
+    RJ_KLAUNCH(L, "pass2_hist", (k_pass_hist<PackedLoader>), n_groups, PT_THREADS, ld, pp);
 }
 
 void launch_pass_scatter_src_packed(const Launch& L, const TupleSrc& src, const PassParams& pp,

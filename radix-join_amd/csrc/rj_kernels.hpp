@@ -57,6 +57,8 @@ void launch_pass_scatter_dense(const Launch& L, const Words& in, int n_words, co
                                uint32_t n_groups, const Words& out);
 
 // Packed layout ({hashed key, carry} pairs in one array) for one key word + one carry word.
+void launch_pass_hist_packed(const Launch& L, const uint32_t* in_pairs, const PassParams& pp,
+                             uint32_t n_groups);
 void launch_pass_scatter_src_packed(const Launch& L, const TupleSrc& src, const PassParams& pp,
                                     uint32_t n_groups, uint32_t* out_pairs);
 void launch_pass_scatter_packed(const Launch& L, const uint32_t* in_pairs, const PassParams& pp,
