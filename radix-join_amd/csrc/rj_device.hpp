@@ -148,7 +148,7 @@ struct JoinParams {
     uint64_t        out_cap;     // rows that fit the stream buffers
     const uint32_t* heavy_tasks; // [n][3] = {partition, s_begin, s_end}
     const uint32_t* n_heavy;
-    int32_t         heavy_pass;  // 0: one workgroup per partition; 1: heavy task list
+    uint32_t        heavy_grid;  // the first heavy_grid workgroups of the launch take heavy tasks
     int32_t         packR, packS; // R.w[0] / S.w[0] is an array of {hashed key, carry} pairs
     int32_t         pad;
     unsigned long long* diag;    // phase cycle counters (RJ_DIAG=1 only), else nullptr

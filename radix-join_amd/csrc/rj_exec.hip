@@ -619,8 +619,9 @@ class Exec {
                 RJ_HIP(hipMemsetAsync(diag->p, 0, 16 * 8, ctx->stream));
                 jp.diag = diag->as<unsigned long long>();
             }
-            jp.heavy_pass = 0;
-            launch_join(L, KW, bs.CW, ps.CW, jp, (PB.NP + JN_PPW - 1) / JN_PPW);
+            // one launch: heavy-task workgroups first, then one workgroup per partition
+            jp.heavy_grid = max_tasks;
+            launch_join(L, KW, bs.CW, ps.CW, jp, max_tasks + (PB.NP + JN_PPW - 1) / JN_PPW);
             if (diag) {
                 unsigned long long hd[16];
                 RJ_HIP(hipMemcpyAsync(hd, diag->p, sizeof hd, hipMemcpyDeviceToHost, ctx->stream));
@@ -635,8 +636,6 @@ class Exec {
                             100.0 * hd[i] / tot, (double)hd[i] / PB.NP);
                 jp.diag = nullptr;
             }
-            jp.heavy_pass = 1;
-            launch_join(L, KW, bs.CW, ps.CW, jp, max_tasks);
             // Page headers of the streams the probe wrote straight into Page images: done on
             // the device from the device-side row count, so nothing waits for the read-back
             finished.clear();

@@ -897,20 +897,24 @@ __global__ __launch_bounds__(JN_THREADS, jn_min_waves(KW + (CWR == 2 ? 1 : CWR))
         uint32_t q, rbeg, rend, sbeg, send;
         bool     active;
     };
+    // The first jp.heavy_grid workgroups of the launch take the heavy tasks (they start first:
+    // with a skewed probe side they are the long pole), the others one partition each.
+    const bool     heavy_wg = blockIdx.x < jp.heavy_grid;
+    const uint32_t wg = heavy_wg ? blockIdx.x : blockIdx.x - jp.heavy_grid;
     auto get_task = [&](uint32_t k) {
         Task t{0, 0, 0, 0, 0, false};
-        if (jp.heavy_pass) {
-            if (k == 0 && blockIdx.x < *jp.n_heavy) {
-                t.q = jp.heavy_tasks[3 * blockIdx.x + 0];
-                t.sbeg = jp.heavy_tasks[3 * blockIdx.x + 1];
-                t.send = jp.heavy_tasks[3 * blockIdx.x + 2];
+        if (heavy_wg) {
+            if (k == 0 && wg < *jp.n_heavy) {
+                t.q = jp.heavy_tasks[3 * wg + 0];
+                t.sbeg = jp.heavy_tasks[3 * wg + 1];
+                t.send = jp.heavy_tasks[3 * wg + 2];
                 t.rbeg = jp.offR[t.q];
                 t.rend = jp.offR[t.q + 1];
                 t.active = t.rbeg < t.rend && t.sbeg < t.send;
             }
             return t;
         }
-        t.q = blockIdx.x * JN_PPW + k;
+        t.q = wg * JN_PPW + k;
         if (k < JN_PPW && t.q < jp.NP) {
             t.rbeg = jp.offR[t.q];
             t.rend = jp.offR[t.q + 1];
@@ -1050,7 +1054,7 @@ __global__ __launch_bounds__(JN_THREADS, jn_min_waves(KW + (CWR == 2 ? 1 : CWR))
     };
 
     unsigned long long diag_t = jp.diag ? __builtin_amdgcn_s_memtime() : 0ull;
-    const uint32_t     n_tasks = jp.heavy_pass ? 1u : (uint32_t)JN_PPW;
+    const uint32_t     n_tasks = heavy_wg ? 1u : (uint32_t)JN_PPW;
     Task               cur = get_task(0);
     // haveR / haveS: the first build chunk / first probe sub-chunk of `cur` already sit in
     // rw / sw (prefetched while the previous partition was being probed / before its build)
@@ -1558,7 +1562,7 @@ void launch_heavy_tasks(const Launch& L, const uint32_t* offR, const uint32_t* o
 
 template <int KW, int CWR, int CWS, int PK>
 static void join_pk(const Launch& L, const JoinParams& jp, uint32_t grid) {
-    const char* name = jp.heavy_pass ? "join_heavy" : "join_build_probe";
+    const char* name = "join_build_probe";
     // pick the straight-line emit variant when the stream layout allows it
     int om = OM_GENERIC;
     if (KW == 1 && CWR <= 1 && CWS <= 1) {
