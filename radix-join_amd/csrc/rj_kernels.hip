@@ -490,6 +490,19 @@ struct SrcLoader {
         ok = drop_invalid(vec, base, end, ok);
         return hash_keys(ok, hk, hi);
     }
+    // The same in two halves, for a software pipeline: issue_keys only ISSUES the loads of the
+    // raw key words, finish_keys (which needs the data) drops invalid rows and hashes.
+    __device__ __forceinline__ uint32_t issue_keys(uint32_t base, uint32_t end,
+                                                   uint32_t (&lo)[PT_ITEMS],
+                                                   uint32_t (&hi)[PT_ITEMS]) const {
+        return raw_keys(base + PT_TILE <= end, base, end, lo, hi);
+    }
+    __device__ __forceinline__ uint32_t finish_keys(uint32_t base, uint32_t end, uint32_t ok,
+                                                    uint32_t (&lo)[PT_ITEMS],
+                                                    uint32_t (&hi)[PT_ITEMS]) const {
+        ok = drop_invalid(base + PT_TILE <= end, base, end, ok);
+        return hash_keys(ok, lo, hi);
+    }
     template <int NW>
     __device__ __forceinline__ uint32_t load_tile(uint32_t base, uint32_t end,
                                                   uint32_t (&w)[PT_ITEMS][NW]) const {
@@ -598,15 +611,24 @@ __global__ __launch_bounds__(PT_THREADS) void k_fine_hist(Loader ld, uint32_t n,
     for (uint32_t d = threadIdx.x; d < NB; d += PT_THREADS) s_f[d] = 0;
     lds_barrier();
     const uint32_t tiles = (uint32_t)(((uint64_t)n + PT_TILE - 1) / PT_TILE);
+    // Software pipeline: the LDS atomics of a tile (a third of its time) run while the NEXT
+    // tile's loads are in flight — the raw loads are issued before the atomics, hashing (which
+    // needs the data) comes after them.
+    uint32_t lo[PT_ITEMS], hi[PT_ITEMS], raw = 0;
+    if (blockIdx.x < tiles) raw = ld.issue_keys(blockIdx.x * (uint32_t)PT_TILE, n, lo, hi);
     for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x) {
-        uint32_t hk[PT_ITEMS];
-        uint32_t ok = ld.key_tile(t * (uint32_t)PT_TILE, n, hk);
+        const uint32_t ok = ld.finish_keys(t * (uint32_t)PT_TILE, n, raw, lo, hi);
+        uint32_t       q[PT_ITEMS];
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS; ++j) {
+            const uint32_t h = lo[j] >> shift;
+            q[j] = ((h & m1) << b2) | ((h >> b1) & m2);
+        }
+        const uint32_t t2 = t + gridDim.x;
+        if (t2 < tiles) raw = ld.issue_keys(t2 * (uint32_t)PT_TILE, n, lo, hi);
 #pragma unroll
         for (int j = 0; j < PT_ITEMS; ++j)
-            if ((ok >> j) & 1u) {
-                const uint32_t h = hk[j] >> shift;
-                atomicAdd(&s_f[((h & m1) << b2) | ((h >> b1) & m2)], 1u);
-            }
+            if ((ok >> j) & 1u) atomicAdd(&s_f[q[j]], 1u);
     }
     lds_barrier();
     for (uint32_t d = threadIdx.x; d < NB; d += PT_THREADS) {
