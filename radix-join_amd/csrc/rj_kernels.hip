@@ -319,6 +319,7 @@ struct DenseLoader {
 // Partitioned tuples of ONE key word + ONE carry word can also be kept packed: an array of
 // 8-byte {hashed key, carry} pairs instead of two word arrays (see k_pass_scatter_packed).
 struct PackedLoader {
+    static constexpr bool kPrefetch = true;  // load_tile has no post-processing: safe to issue early
     const uint2* in;
     // keys only (histogram of a later pass): every second word of the pairs
     __device__ __forceinline__ uint32_t key_tile(uint32_t base, uint32_t end,
@@ -386,6 +387,7 @@ __device__ __forceinline__ uint64_t col_off64(bool paged, uint32_t row) {
 // are valid) and hashing fused into the first radix pass.
 template <int KW, int CW>
 struct SrcLoader {
+    static constexpr bool kPrefetch = false;
     TupleSrc s;
 
     // Row of item j.  Full tiles use the vector mapping (four consecutive rows per thread
@@ -790,13 +792,17 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter_packed(Loader ld, P
     const uint32_t F = 1u << pp.fanout_log2, mask = F - 1u;
 
     uint32_t run = 0;  // thread d: where digit d's run of the current tile starts in the output
+    // kPrefetch loaders: the next tile's loads are issued as soon as this tile has been staged
+    // (its registers are dead then) and fly during the copy-out
+    uint32_t w[PT_ITEMS][2];
+    uint32_t ok = 0;
+    if constexpr (Loader::kPrefetch) ok = ld.template load_tile<2>(begin, end, w);
     for (uint32_t base = begin; base < end; base += PT_TILE) {
         for (uint32_t d = threadIdx.x; d < F; d += PT_THREADS) s_cnt[d] = 0;
         lds_barrier();
 
-        uint32_t       w[PT_ITEMS][2];
-        uint32_t       dr[PT_ITEMS];  // digit << 16 | rank, 0xffffffff = no tuple
-        const uint32_t ok = ld.template load_tile<2>(base, end, w);
+        uint32_t dr[PT_ITEMS];  // digit << 16 | rank, 0xffffffff = no tuple
+        if constexpr (!Loader::kPrefetch) ok = ld.template load_tile<2>(base, end, w);
 #pragma unroll
         for (int j = 0; j < PT_ITEMS; ++j) {
             dr[j] = 0xffffffffu;
@@ -819,6 +825,9 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter_packed(Loader ld, P
         for (int j = 0; j < PT_ITEMS; ++j)
             if (dr[j] != 0xffffffffu)
                 s_stage[s_base[dr[j] >> 16] + (dr[j] & 0xffffu)] = make_uint2(w[j][0], w[j][1]);
+        if constexpr (Loader::kPrefetch) {
+            if (base + PT_TILE < end) ok = ld.template load_tile<2>(base + PT_TILE, end, w);
+        }
         if (threadIdx.x < F) s_delta[threadIdx.x] = run - ex;  // global index = delta + LDS position
         lds_barrier();
 
