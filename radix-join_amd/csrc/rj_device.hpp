@@ -154,4 +154,12 @@ struct JoinParams {
     unsigned long long* diag;    // phase cycle counters (RJ_DIAG=1 only), else nullptr
 };
 
+// ---- Broadcast join (build side fits ONE LDS table): no partitioning at all --------------
+struct BcastParams {
+    TupleSrc        R, S;        // build / probe tuples straight from the child columns
+    OutStream       key, bc, pc; // emitted streams: key, build carry, probe carry
+    unsigned long long* out_cursor;
+    uint64_t        out_cap;
+};
+
 }  // namespace rj

@@ -368,273 +368,298 @@ class Exec {
                 uint64_t gt = (uint64_t)pp.tiles_per_group * PT_TILE;
                 n_groups = (uint32_t)((n + gt - 1) / gt);
             } else {
-                pp.tiles_per_group = tiles_per_group(n / nseg + 1, 16);
-                uint64_t gt = (uint64_t)pp.tiles_per_group * PT_TILE;
-                n_groups = (uint32_t)(n / gt + nseg);  // upper bound; exact count lives on device
-                grp_start = ctx->buf(((uint64_t)nseg + 1) * 4);
-                launch_group_table(L, seg_off->as<uint32_t>(), nseg, (uint32_t)gt,
-                                   grp_start->as<uint32_t>());
-                pp.seg_off = seg_off->as<uint32_t>();
-                pp.grp_start = grp_start->as<uint32_t>();
+                    pp.tiles_per_group = tiles_per_group(n / nseg + 1, 16);
+                    uint64_t gt = (uint64_t)pp.tiles_per_group * PT_TILE;
+                    n_groups = (uint32_t)(n / gt + nseg);  // upper bound; exact count lives on device
+                    grp_start = ctx->buf(((uint64_t)nseg + 1) * 4);
+                    launch_group_table(L, seg_off->as<uint32_t>(), nseg, (uint32_t)gt,
+                                       grp_start->as<uint32_t>());
+                    pp.seg_off = seg_off->as<uint32_t>();
+                    pp.grp_start = grp_start->as<uint32_t>();
+                }
+                BufP off, hist, cursor;  // this pass' partition offsets, bin totals, write cursors
+                if (fine) {  // offsets and cursors of both passes came out of the fine histogram
+                    off = p == 0 ? coarse_off : fine_off;
+                    cursor = p == 0 ? coarse_cursor : fine_cursor;
+                    pp.cursor = cursor->as<uint32_t>();
+                } else {
+                    hist = ctx->buf(bins * 4);
+                    off = ctx->buf((bins + 1) * 4);
+                    cursor = ctx->buf(bins * 4);
+                    RJ_HIP(hipMemsetAsync(hist->p, 0, bins * 4, ctx->stream));
+                    pp.hist = hist->as<uint32_t>();
+                    pp.cursor = cursor->as<uint32_t>();
+                    if (p == 0)
+                        launch_pass_hist_src(L, src, KW, pp, n_groups);
+                    else if (P.packed)
+                        launch_pass_hist_packed(L, cur.w[0], pp, n_groups);
+                    else
+                        launch_pass_hist_dense(L, cur, pp, n_groups);
+                    launch_scan_segments(L, pp.hist, p == 0 ? nullptr : pp.seg_off, nseg, F,
+                                         off->as<uint32_t>(), pp.cursor);
+                }
+                if (P.packed) {
+                    if (p == 0)
+                        launch_pass_scatter_src_packed(L, src, pp, n_groups, nxt.w[0]);
+                    else
+                        launch_pass_scatter_packed(L, cur.w[0], pp, n_groups, nxt.w[0]);
+                } else if (p == 0) {
+                    launch_pass_scatter_src(L, src, KW, CW, pp, n_groups, nxt);
+                } else {
+                    launch_pass_scatter_dense(L, cur, P.NW, pp, n_groups, nxt);
+                }
+                seg_off = off;
+                nseg = (uint32_t)bins;
+                shift += pbits[p];
+                cur = nxt;
+                cur_is_a = (p % 2 == 0);
+                nxt = cur_is_a ? wb : wa;
             }
-            BufP off, hist, cursor;  // this pass' partition offsets, bin totals, write cursors
-            if (fine) {  // offsets and cursors of both passes came out of the fine histogram
-                off = p == 0 ? coarse_off : fine_off;
-                cursor = p == 0 ? coarse_cursor : fine_cursor;
-                pp.cursor = cursor->as<uint32_t>();
-            } else {
-                hist = ctx->buf(bins * 4);
-                off = ctx->buf((bins + 1) * 4);
-                cursor = ctx->buf(bins * 4);
-                RJ_HIP(hipMemsetAsync(hist->p, 0, bins * 4, ctx->stream));
-                pp.hist = hist->as<uint32_t>();
-                pp.cursor = cursor->as<uint32_t>();
-                if (p == 0)
-                    launch_pass_hist_src(L, src, KW, pp, n_groups);
-                else if (P.packed)
-                    launch_pass_hist_packed(L, cur.w[0], pp, n_groups);
-                else
-                    launch_pass_hist_dense(L, cur, pp, n_groups);
-                launch_scan_segments(L, pp.hist, p == 0 ? nullptr : pp.seg_off, nseg, F,
-                                     off->as<uint32_t>(), pp.cursor);
-            }
-            if (P.packed) {
-                if (p == 0)
-                    launch_pass_scatter_src_packed(L, src, pp, n_groups, nxt.w[0]);
-                else
-                    launch_pass_scatter_packed(L, cur.w[0], pp, n_groups, nxt.w[0]);
-            } else if (p == 0) {
-                launch_pass_scatter_src(L, src, KW, CW, pp, n_groups, nxt);
-            } else {
-                launch_pass_scatter_dense(L, cur, P.NW, pp, n_groups, nxt);
-            }
-            seg_off = off;
-            nseg = (uint32_t)bins;
-            shift += pbits[p];
-            cur = nxt;
-            cur_is_a = (p % 2 == 0);
-            nxt = cur_is_a ? wb : wa;
+            P.w = cur;
+            for (int a = 0; a < P.NW; ++a) P.wbuf[a] = cur_is_a ? A[a] : B[a];
+            P.off = seg_off;
+            P.NP = nseg;
+            P.pbits = pbits;
+            return P;
         }
-        P.w = cur;
-        for (int a = 0; a < P.NW; ++a) P.wbuf[a] = cur_is_a ? A[a] : B[a];
-        P.off = seg_off;
-        P.NP = nseg;
-        P.pbits = pbits;
-        return P;
-    }
 
-    // ---------------------------------------------------------------- join
-    struct Side {
-        Rel*          rel = nullptr;
-        uint64_t      key_col = 0;
-        std::set<int> need;       // referenced columns that are not served by the key stream
-        int           carry_mode = CARRY_NONE;
-        int           carry_col = -1;
-        int           CW = 0;
-        BufP          stream;     // emitted carry stream
-        int           stream_mode = ST_NONE;
-    };
+        // ---------------------------------------------------------------- join
+        struct Side {
+            Rel*          rel = nullptr;
+            uint64_t      key_col = 0;
+            std::set<int> need;       // referenced columns that are not served by the key stream
+            int           carry_mode = CARRY_NONE;
+            int           carry_col = -1;
+            int           CW = 0;
+            BufP          stream;     // emitted carry stream
+            int           stream_mode = ST_NONE;
+        };
 
-    static uint64_t pages_for(uint64_t rows, int width) {
-        uint64_t rf = width == 4 ? ROWS32 : ROWS64;
-        return (rows + rf - 1) / rf;
-    }
-
-    Rel empty_rel(const JoinSpec& js, Result* root_res) {
-        Rel r;
-        r.n = 0;
-        for (size_t k = 0; k < js.out_type.size(); ++k) {
-            DCol d;
-            d.type = js.out_type[k];
-            d.kind = COL_DENSE;
-            d.width = d.type == RJ_INT32 || d.type == RJ_VARCHAR ? 4 : 8;
-            r.cols.push_back(d);
+        static uint64_t pages_for(uint64_t rows, int width) {
+            uint64_t rf = width == 4 ? ROWS32 : ROWS64;
+            return (rows + rf - 1) / rf;
         }
-        if (root_res) {
-            root_res->num_rows = 0;
+
+        Rel empty_rel(const JoinSpec& js, Result* root_res) {
+            Rel r;
+            r.n = 0;
             for (size_t k = 0; k < js.out_type.size(); ++k) {
-                ResultColumn rc;
-                rc.type = js.out_type[k];
-                root_res->cols.push_back(std::move(rc));
+                DCol d;
+                d.type = js.out_type[k];
+                d.kind = COL_DENSE;
+                d.width = d.type == RJ_INT32 || d.type == RJ_VARCHAR ? 4 : 8;
+                r.cols.push_back(d);
             }
-        }
-        return r;
-    }
-
-    // execute_hash_join + hash_join_omp (reference src/execute.cpp:43-282)
-    Rel join_core(Rel& left, Rel& right, const JoinSpec& js, Result* root_res) {
-        const size_t lw = left.cols.size(), rw = right.cols.size();
-        const bool   is_root = root_res != nullptr;
-        // with an empty child the reference returns {} before looking at anything (:50)
-        if (left.n == 0 || right.n == 0) return empty_rel(js, root_res);
-        if (js.left_attr >= lw || js.right_attr >= rw)
-            throw_fmt(RJ_ERR_ARG, "join: key attr out of range");
-        for (size_t k = 0; k < js.out_idx.size(); ++k) {
-            if (js.out_idx[k] >= lw + rw) throw_fmt(RJ_ERR_ARG, "join: output attr out of range");
-            const DCol& c = js.out_idx[k] < lw ? left.cols[js.out_idx[k]]
-                                               : right.cols[js.out_idx[k] - lw];
-            if (c.type != js.out_type[k])
-                throw_fmt(RJ_ERR_ARG, "join: declared type differs from the child column's type");
-        }
-        Side  ls, rs;
-        ls.rel = &left;
-        ls.key_col = js.left_attr;
-        rs.rel = &right;
-        rs.key_col = js.right_attr;
-        Side&       bs = js.build_left ? ls : rs;
-        Side&       ps = js.build_left ? rs : ls;
-        const DCol& bk = bs.rel->cols[bs.key_col];
-        const DCol& pk = ps.rel->cols[ps.key_col];
-        // KeyType = build side's key type (:271-273)
-        if (bk.type == RJ_VARCHAR)
-            throw_fmt(RJ_ERR_UNSUPPORTED,
-                      "VARCHAR join keys are not supported on the GPU path (never a JOB join key)");
-        if (bk.type < RJ_INT32 || bk.type > RJ_VARCHAR) throw_fmt(RJ_ERR_ARG, "Unsupported join type");
-        // probe values of another variant alternative are never valid (:65-71)
-        if (pk.type != bk.type) return empty_rel(js, root_res);
-        const int  KW = bk.type == RJ_INT32 ? 1 : 2;
-        const bool f64 = bk.type == RJ_FP64;
-        // matching keys are bit-identical on both sides (FP64 included: bit-pattern equality,
-        // see SrcLoader::key2), so one emitted key stream serves either side's key column
-        const bool key_stream_ok = true;
-
-        // which child columns must each side deliver?
-        bool need_key_stream = false;
-        for (size_t k = 0; k < js.out_idx.size(); ++k) {
-            bool  is_left = js.out_idx[k] < lw;
-            Side& s = is_left ? ls : rs;
-            int   c = (int)(is_left ? js.out_idx[k] : js.out_idx[k] - lw);
-            if (key_stream_ok && (uint64_t)c == s.key_col)
-                need_key_stream = true;
-            else
-                s.need.insert(c);
-        }
-        for (Side* s : {&ls, &rs}) {
-            if (s->need.empty()) {
-                s->carry_mode = CARRY_NONE;
-                s->CW = 0;
-            } else if (s->need.size() == 1 && s->rel->cols[*s->need.begin()].valid == nullptr) {
-                s->carry_mode = CARRY_COLUMN;
-                s->carry_col = *s->need.begin();
-                s->CW = s->rel->cols[s->carry_col].width / 4;
-            } else {
-                s->carry_mode = CARRY_ROWIDX;
-                s->CW = 1;
+            if (root_res) {
+                root_res->num_rows = 0;
+                for (size_t k = 0; k < js.out_type.size(); ++k) {
+                    ResultColumn rc;
+                    rc.type = js.out_type[k];
+                    root_res->cols.push_back(std::move(rc));
+                }
             }
+            return r;
         }
 
-        // radix bit plan from the build cardinality
-        uint32_t bits = js.forced_bits > 0
-                            ? (uint32_t)js.forced_bits
-                            : ceil_log2((bs.rel->n + JN_TARGET_BUILD - 1) / JN_TARGET_BUILD);
-        // a third pass costs 20 B/tuple more than slightly fuller tables: stay at two passes
-        // (2 * PT_MAXBITS bits) while the mean build partition still fits the LDS table with
-        // a margin (rare larger partitions are joined in table-sized chunks anyway)
-        if (js.forced_bits <= 0 && bits > 2 * PT_MAXBITS &&
-            (bs.rel->n >> (2 * PT_MAXBITS)) <= (uint64_t)(JN_RMAX * 0.95))
-            bits = 2 * PT_MAXBITS;
-        bits = std::min<uint32_t>(std::max<uint32_t>(bits, 1), 27);
-
-        auto make_src = [&](Side& s) {
-            TupleSrc src{};
-            src.key = s.rel->cols[s.key_col].ref();
-            src.n_rows = (uint32_t)s.rel->n;
-            src.carry_mode = s.carry_mode;
-            if (s.carry_mode == CARRY_COLUMN) {
-                src.carry = s.rel->cols[s.carry_col].ref();
-                // a base table's row-id column (VARCHAR stand-in) IS the row index
-                if (src.carry.kind == COL_IOTA) src.carry_mode = CARRY_ROWIDX;
+        // execute_hash_join + hash_join_omp (reference src/execute.cpp:43-282)
+        Rel join_core(Rel& left, Rel& right, const JoinSpec& js, Result* root_res) {
+            const size_t lw = left.cols.size(), rw = right.cols.size();
+            const bool   is_root = root_res != nullptr;
+            // with an empty child the reference returns {} before looking at anything (:50)
+            if (left.n == 0 || right.n == 0) return empty_rel(js, root_res);
+            if (js.left_attr >= lw || js.right_attr >= rw)
+                throw_fmt(RJ_ERR_ARG, "join: key attr out of range");
+            for (size_t k = 0; k < js.out_idx.size(); ++k) {
+                if (js.out_idx[k] >= lw + rw) throw_fmt(RJ_ERR_ARG, "join: output attr out of range");
+                const DCol& c = js.out_idx[k] < lw ? left.cols[js.out_idx[k]]
+                                                   : right.cols[js.out_idx[k] - lw];
+                if (c.type != js.out_type[k])
+                    throw_fmt(RJ_ERR_ARG, "join: declared type differs from the child column's type");
             }
-            src.key_f64 = f64 ? 1 : 0;
-            src.prehashed = js.prehashed ? 1 : 0;
-            return src;
-        };
-        Parted PB = partition(make_src(bs), KW, bs.CW, bits);
-        Parted PP = partition(make_src(ps), KW, ps.CW, bits);
+            Side  ls, rs;
+            ls.rel = &left;
+            ls.key_col = js.left_attr;
+            rs.rel = &right;
+            rs.key_col = js.right_attr;
+            Side&       bs = js.build_left ? ls : rs;
+            Side&       ps = js.build_left ? rs : ls;
+            const DCol& bk = bs.rel->cols[bs.key_col];
+            const DCol& pk = ps.rel->cols[ps.key_col];
+            // KeyType = build side's key type (:271-273)
+            if (bk.type == RJ_VARCHAR)
+                throw_fmt(RJ_ERR_UNSUPPORTED,
+                          "VARCHAR join keys are not supported on the GPU path (never a JOB join key)");
+            if (bk.type < RJ_INT32 || bk.type > RJ_VARCHAR) throw_fmt(RJ_ERR_ARG, "Unsupported join type");
+            // probe values of another variant alternative are never valid (:65-71)
+            if (pk.type != bk.type) return empty_rel(js, root_res);
+            const int  KW = bk.type == RJ_INT32 ? 1 : 2;
+            const bool f64 = bk.type == RJ_FP64;
+            // matching keys are bit-identical on both sides (FP64 included: bit-pattern equality,
+            // see SrcLoader::key2), so one emitted key stream serves either side's key column
+            const bool key_stream_ok = true;
 
-        // heavy probe partitions -> task list
-        uint32_t max_tasks = (uint32_t)(2 * (ps.rel->n / JN_HEAVY) + 2);
-        BufP     tasks = ctx->buf((uint64_t)max_tasks * 12);
-        BufP     counters = ctx->buf(16);  // [0..7] out cursor (u64), [8..11] n_heavy
-        launch_heavy_tasks_zeroed(PB, PP, tasks, counters, max_tasks);
+            // which child columns must each side deliver?
+            bool need_key_stream = false;
+            for (size_t k = 0; k < js.out_idx.size(); ++k) {
+                bool  is_left = js.out_idx[k] < lw;
+                Side& s = is_left ? ls : rs;
+                int   c = (int)(is_left ? js.out_idx[k] : js.out_idx[k] - lw);
+                if (key_stream_ok && (uint64_t)c == s.key_col)
+                    need_key_stream = true;
+                else
+                    s.need.insert(c);
+            }
+            for (Side* s : {&ls, &rs}) {
+                if (s->need.empty()) {
+                    s->carry_mode = CARRY_NONE;
+                    s->CW = 0;
+                } else if (s->need.size() == 1 && s->rel->cols[*s->need.begin()].valid == nullptr) {
+                    s->carry_mode = CARRY_COLUMN;
+                    s->carry_col = *s->need.begin();
+                    s->CW = s->rel->cols[s->carry_col].width / 4;
+                } else {
+                    s->carry_mode = CARRY_ROWIDX;
+                    s->CW = 1;
+                }
+            }
 
-        // stream destinations
-        auto stream_mode = [&](int width, bool direct_output) -> int {
-            if (is_root && direct_output) return width == 4 ? ST_PAGED32 : ST_PAGED64;
-            return width == 4 ? ST_DENSE32 : ST_DENSE64;
-        };
-        auto stream_bytes = [&](int mode, uint64_t rows) -> uint64_t {
-            switch (mode) {
-            case ST_DENSE32: return rows * 4;
-            case ST_DENSE64: return rows * 8;
-            case ST_PAGED32: return pages_for(rows, 4) * PAGE_BYTES;
-            case ST_PAGED64: return pages_for(rows, 8) * PAGE_BYTES;
-            default: return 0;
-            }
-        };
-        int key_mode = need_key_stream ? stream_mode(KW * 4, true) : ST_NONE;
-        for (Side* s : {&ls, &rs}) {
-            if (s->carry_mode == CARRY_NONE)
-                s->stream_mode = ST_NONE;
-            else if (s->carry_mode == CARRY_ROWIDX)
-                s->stream_mode = ST_DENSE32;
-            else {
-                const DCol& c = s->rel->cols[s->carry_col];
-                s->stream_mode = stream_mode(c.width, c.type != RJ_VARCHAR);
-            }
-        }
+            // radix bit plan from the build cardinality
+            uint32_t bits = js.forced_bits > 0
+                                ? (uint32_t)js.forced_bits
+                                : ceil_log2((bs.rel->n + JN_TARGET_BUILD - 1) / JN_TARGET_BUILD);
+            // a third pass costs 20 B/tuple more than slightly fuller tables: stay at two passes
+            // (2 * PT_MAXBITS bits) while the mean build partition still fits the LDS table with
+            // a margin (rare larger partitions are joined in table-sized chunks anyway)
+            if (js.forced_bits <= 0 && bits > 2 * PT_MAXBITS &&
+                (bs.rel->n >> (2 * PT_MAXBITS)) <= (uint64_t)(JN_RMAX * 0.95))
+                bits = 2 * PT_MAXBITS;
+            bits = std::min<uint32_t>(std::max<uint32_t>(bits, 1), 27);
+            if (tune("RJ_DIAG", 0) >= 2)
+                fprintf(stderr, "[rj diag] join build=%llu probe=%llu bits=%u cw=%d/%d\n",
+                        (unsigned long long)bs.rel->n, (unsigned long long)ps.rel->n, bits, bs.CW, ps.CW);
 
-        uint64_t cap = std::max(left.n, right.n);
-        cap = std::min<uint64_t>(cap + 1024, 0xfffffff0ull);
-        BufP            key_stream;
-        uint64_t        nrows = 0;
-        std::set<void*> finished;  // paged buffers that already got their headers
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            key_stream = key_mode != ST_NONE ? ctx->buf(stream_bytes(key_mode, cap)) : BufP();
-            for (Side* s : {&ls, &rs})
-                s->stream = s->stream_mode != ST_NONE ? ctx->buf(stream_bytes(s->stream_mode, cap))
-                                                      : BufP();
-            RJ_HIP(hipMemsetAsync(counters->p, 0, 8, ctx->stream));
-            JoinParams jp{};
-            jp.R = PB.w;
-            jp.S = PP.w;
-            jp.packR = PB.packed ? 1 : 0;
-            jp.packS = PP.packed ? 1 : 0;
-            jp.offR = PB.off->as<uint32_t>();
-            jp.offS = PP.off->as<uint32_t>();
-            jp.NP = PB.NP;
-            jp.radix_bits = bits;
-            jp.n_pass = (uint32_t)PB.pbits.size();
-            for (size_t i = 0; i < PB.pbits.size() && i < 4; ++i) jp.pass_bits[i] = PB.pbits[i];
-            jp.key = OutStream{key_stream ? key_stream->as<uint8_t>() : nullptr, key_mode, 0};
-            jp.bc = OutStream{bs.stream ? bs.stream->as<uint8_t>() : nullptr, bs.stream_mode, 0};
-            jp.pc = OutStream{ps.stream ? ps.stream->as<uint8_t>() : nullptr, ps.stream_mode, 0};
-            jp.out_cursor = counters->as<unsigned long long>();
-            jp.out_cap = cap;
-            jp.heavy_tasks = tasks->as<uint32_t>();
-            jp.n_heavy = counters->as<uint32_t>() + 2;
-            BufP diag;
-            if (tune("RJ_DIAG", 0)) {
-                diag = ctx->buf(16 * 8);
-                RJ_HIP(hipMemsetAsync(diag->p, 0, 16 * 8, ctx->stream));
-                jp.diag = diag->as<unsigned long long>();
+            auto make_src = [&](Side& s) {
+                TupleSrc src{};
+                src.key = s.rel->cols[s.key_col].ref();
+                src.n_rows = (uint32_t)s.rel->n;
+                src.carry_mode = s.carry_mode;
+                if (s.carry_mode == CARRY_COLUMN) {
+                    src.carry = s.rel->cols[s.carry_col].ref();
+                    // a base table's row-id column (VARCHAR stand-in) IS the row index
+                    if (src.carry.kind == COL_IOTA) src.carry_mode = CARRY_ROWIDX;
+                }
+                src.key_f64 = f64 ? 1 : 0;
+                src.prehashed = js.prehashed ? 1 : 0;
+                return src;
+            };
+            // A build side that fits one LDS table is not partitioned at all: every workgroup builds
+            // the same table and streams a slice of the probe child past it (k_join_bcast)
+            const bool bcast = bs.rel->n <= (uint64_t)JN_RMAX && js.forced_bits <= 0 && !js.prehashed &&
+                               tune("RJ_TUNE_BCAST", 1) != 0;
+            Parted   PB, PP;
+            uint32_t max_tasks = 0;
+            BufP     tasks;
+            BufP     counters = ctx->buf(16);  // [0..7] out cursor (u64), [8..11] n_heavy
+            if (!bcast) {
+                PB = partition(make_src(bs), KW, bs.CW, bits);
+                PP = partition(make_src(ps), KW, ps.CW, bits);
+                // heavy probe partitions -> task list
+                max_tasks = (uint32_t)(2 * (ps.rel->n / JN_HEAVY) + 2);
+                tasks = ctx->buf((uint64_t)max_tasks * 12);
+                launch_heavy_tasks_zeroed(PB, PP, tasks, counters, max_tasks);
             }
-            // one launch: heavy-task workgroups first, then one workgroup per partition
-            jp.heavy_grid = max_tasks;
-            launch_join(L, KW, bs.CW, ps.CW, jp, max_tasks + (PB.NP + JN_PPW - 1) / JN_PPW);
-            if (diag) {
-                unsigned long long hd[16];
-                RJ_HIP(hipMemcpyAsync(hd, diag->p, sizeof hd, hipMemcpyDeviceToHost, ctx->stream));
-                ctx->sync();
-                static const char* names[] = {"loads issued", "table clear", "build", "count/probe",
-                                              "prefix+barrier", "reserve", "emit"};
-                double tot = 0;
-                for (int i = 0; i < 7; ++i) tot += (double)hd[i];
-                fprintf(stderr, "[rj diag] join phases (cycles of thread 0, summed over %u workgroups):\n", PB.NP);
-                for (int i = 0; i < 7; ++i)
-                    fprintf(stderr, "[rj diag]   %-16s %6.1f %%  %8.0f cyc/wg\n", names[i],
-                            100.0 * hd[i] / tot, (double)hd[i] / PB.NP);
-                jp.diag = nullptr;
+
+            // stream destinations
+            auto stream_mode = [&](int width, bool direct_output) -> int {
+                if (is_root && direct_output) return width == 4 ? ST_PAGED32 : ST_PAGED64;
+                return width == 4 ? ST_DENSE32 : ST_DENSE64;
+            };
+            auto stream_bytes = [&](int mode, uint64_t rows) -> uint64_t {
+                switch (mode) {
+                case ST_DENSE32: return rows * 4;
+                case ST_DENSE64: return rows * 8;
+                case ST_PAGED32: return pages_for(rows, 4) * PAGE_BYTES;
+                case ST_PAGED64: return pages_for(rows, 8) * PAGE_BYTES;
+                default: return 0;
+                }
+            };
+            int key_mode = need_key_stream ? stream_mode(KW * 4, true) : ST_NONE;
+            for (Side* s : {&ls, &rs}) {
+                if (s->carry_mode == CARRY_NONE)
+                    s->stream_mode = ST_NONE;
+                else if (s->carry_mode == CARRY_ROWIDX)
+                    s->stream_mode = ST_DENSE32;
+                else {
+                    const DCol& c = s->rel->cols[s->carry_col];
+                    s->stream_mode = stream_mode(c.width, c.type != RJ_VARCHAR);
+                }
+            }
+
+            uint64_t cap = std::max(left.n, right.n);
+            cap = std::min<uint64_t>(cap + 1024, 0xfffffff0ull);
+            BufP            key_stream;
+            uint64_t        nrows = 0;
+            std::set<void*> finished;  // paged buffers that already got their headers
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                key_stream = key_mode != ST_NONE ? ctx->buf(stream_bytes(key_mode, cap)) : BufP();
+                for (Side* s : {&ls, &rs})
+                    s->stream = s->stream_mode != ST_NONE ? ctx->buf(stream_bytes(s->stream_mode, cap))
+                                                          : BufP();
+                RJ_HIP(hipMemsetAsync(counters->p, 0, 8, ctx->stream));
+                if (bcast) {
+                    BcastParams bp{};
+                    bp.R = make_src(bs);
+                    bp.S = make_src(ps);
+                    bp.key = OutStream{key_stream ? key_stream->as<uint8_t>() : nullptr, key_mode, 0};
+                    bp.bc = OutStream{bs.stream ? bs.stream->as<uint8_t>() : nullptr, bs.stream_mode, 0};
+                    bp.pc = OutStream{ps.stream ? ps.stream->as<uint8_t>() : nullptr, ps.stream_mode, 0};
+                    bp.out_cursor = counters->as<unsigned long long>();
+                    bp.out_cap = cap;
+                    const uint64_t chunks = (ps.rel->n + JN_SUB - 1) / JN_SUB;
+                    launch_join_bcast(L, KW, bs.CW, ps.CW, bp,
+                                      (uint32_t)std::min<uint64_t>(chunks, (uint64_t)ctx->compute_units() * 8));
+                } else {
+                JoinParams jp{};
+                jp.R = PB.w;
+                jp.S = PP.w;
+                jp.packR = PB.packed ? 1 : 0;
+                jp.packS = PP.packed ? 1 : 0;
+                jp.offR = PB.off->as<uint32_t>();
+                jp.offS = PP.off->as<uint32_t>();
+                jp.NP = PB.NP;
+                jp.radix_bits = bits;
+                jp.n_pass = (uint32_t)PB.pbits.size();
+                for (size_t i = 0; i < PB.pbits.size() && i < 4; ++i) jp.pass_bits[i] = PB.pbits[i];
+                jp.key = OutStream{key_stream ? key_stream->as<uint8_t>() : nullptr, key_mode, 0};
+                jp.bc = OutStream{bs.stream ? bs.stream->as<uint8_t>() : nullptr, bs.stream_mode, 0};
+                jp.pc = OutStream{ps.stream ? ps.stream->as<uint8_t>() : nullptr, ps.stream_mode, 0};
+                jp.out_cursor = counters->as<unsigned long long>();
+                jp.out_cap = cap;
+                jp.heavy_tasks = tasks->as<uint32_t>();
+                jp.n_heavy = counters->as<uint32_t>() + 2;
+                BufP diag;
+                if (tune("RJ_DIAG", 0)) {
+                    diag = ctx->buf(16 * 8);
+                    RJ_HIP(hipMemsetAsync(diag->p, 0, 16 * 8, ctx->stream));
+                    jp.diag = diag->as<unsigned long long>();
+                }
+                // one launch: heavy-task workgroups first, then one workgroup per partition
+                jp.heavy_grid = max_tasks;
+                launch_join(L, KW, bs.CW, ps.CW, jp, max_tasks + (PB.NP + JN_PPW - 1) / JN_PPW);
+                if (diag) {
+                    unsigned long long hd[16];
+                    RJ_HIP(hipMemcpyAsync(hd, diag->p, sizeof hd, hipMemcpyDeviceToHost, ctx->stream));
+                    ctx->sync();
+                    static const char* names[] = {"loads issued", "table clear", "build", "count/probe",
+                                                  "prefix+barrier", "reserve", "emit"};
+                    double tot = 0;
+                    for (int i = 0; i < 7; ++i) tot += (double)hd[i];
+                    fprintf(stderr, "[rj diag] join phases (cycles of thread 0, summed over %u workgroups):\n", PB.NP);
+                    for (int i = 0; i < 7; ++i)
+                        fprintf(stderr, "[rj diag]   %-16s %6.1f %%  %8.0f cyc/wg\n", names[i],
+                                100.0 * hd[i] / tot, (double)hd[i] / PB.NP);
+                    jp.diag = nullptr;
+                }
             }
             // Page headers of the streams the probe wrote straight into Page images: done on
             // the device from the device-side row count, so nothing waits for the read-back

@@ -1304,6 +1304,194 @@ __global__ __launch_bounds__(JN_THREADS, jn_min_waves(KW + (CWR == 2 ? 1 : CWR))
     }
 }
 
+// ============================================================ broadcast join
+// A build side of at most JN_RMAX rows (the filtered dimension tables of the JOB plans: a
+// handful of rows against millions) needs no partitioning: every workgroup builds the SAME
+// LDS table straight from the build child's columns and streams a slice of the probe
+// child's columns past it — page decode, NULL-key drop and hashing happen on the way, the
+// probe side is read exactly once and nothing is scattered.  (The reference counterpart is
+// still hash_join_omp, src/execute.cpp:44-262, with num_buckets = 1.)
+// The table keeps key words + the build ROW; build carries are fetched from the build
+// columns on emit (a few KB: cache resident).  With no radix digit to derive an EMPTY
+// sentinel from, a slot is valid when its index is below its bucket's insert counter.
+template <int KW>
+__device__ __forceinline__ bool src_key(const TupleSrc& s, uint32_t row, uint32_t& lo, uint32_t& hi) {
+    bool ok = s.key.valid ? s.key.valid[row] != 0 : true;
+    if constexpr (KW == 1) {
+        uint32_t v = col_load32(s.key, row);
+        lo = s.prehashed ? v : fmix32(v);
+        hi = 0;
+    } else {
+        uint64_t k = col_load64(s.key, row);
+        if (s.key_f64 && (k & 0x7ff0000000000000ull) == 0x7ff0000000000000ull &&
+            (k & 0x000fffffffffffffull))
+            ok = false;  // NaN never matches (see SrcLoader::hash_keys)
+        uint64_t h = fmix64(k);
+        lo = (uint32_t)h;
+        hi = (uint32_t)(h >> 32);
+    }
+    return ok;
+}
+template <int CW>
+__device__ __forceinline__ void src_carry(const TupleSrc& s, uint32_t row, uint32_t& c0, uint32_t& c1) {
+    c0 = c1 = 0;
+    if constexpr (CW >= 1) {
+        if (s.carry_mode == CARRY_ROWIDX) {
+            c0 = row;
+        } else if constexpr (CW == 1) {
+            c0 = col_load32(s.carry, row);
+        } else {
+            uint64_t v = col_load64(s.carry, row);
+            c0 = (uint32_t)v;
+            c1 = (uint32_t)(v >> 32);
+        }
+    }
+}
+
+template <int KW, int CWR, int CWS>
+__global__ __launch_bounds__(JN_THREADS) void k_join_bcast(BcastParams bp) {
+    constexpr int RW = KW + 1;  // key words + build row
+    __shared__ __attribute__((aligned(16))) uint32_t t_w[RW][JN_CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t t_cnt[JN_CAP / 4];
+    __shared__ uint32_t s_wtot[JN_THREADS / 64];
+    __shared__ unsigned long long s_obase;
+    const uint32_t     lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    constexpr uint32_t BMASK = JN_CAP / 4 - 1;
+
+    // ---- build (identical in every workgroup)
+    for (uint32_t i = threadIdx.x; i < JN_CAP / 4; i += JN_THREADS) t_cnt[i] = 0;
+    lds_barrier();
+    for (uint32_t r = threadIdx.x; r < bp.R.n_rows; r += JN_THREADS) {
+        uint32_t lo, hi;
+        if (!src_key<KW>(bp.R, r, lo, hi)) continue;
+        uint32_t b = lo & BMASK;
+        while (true) {
+            uint32_t pos = atomicAdd(&t_cnt[b], 1u);
+            if (pos < 4) {
+                const uint32_t slot = b * 4 + pos;
+                t_w[0][slot] = lo;
+                if constexpr (KW == 2) t_w[1][slot] = hi;
+                t_w[KW][slot] = r;
+                break;
+            }
+            b = (b + 1) & BMASK;
+        }
+    }
+    lds_barrier();
+
+    // matches of one probe key in bucket b: bit mask over its (valid) slots; `more` = the
+    // bucket overflowed, the walk goes on in the next one
+    auto match = [&](uint32_t b, uint32_t lo, uint32_t hi, bool& more) -> uint32_t {
+        const uint32_t cnt = t_cnt[b];
+        const uint4    kv = *reinterpret_cast<const uint4*>(&t_w[0][b * 4]);
+        uint32_t       eq = (uint32_t)(kv.x == lo) | ((uint32_t)(kv.y == lo) << 1) |
+                      ((uint32_t)(kv.z == lo) << 2) | ((uint32_t)(kv.w == lo) << 3);
+        if constexpr (KW == 2) {
+            const uint4 hv = *reinterpret_cast<const uint4*>(&t_w[1][b * 4]);
+            eq &= (uint32_t)(hv.x == hi) | ((uint32_t)(hv.y == hi) << 1) |
+                  ((uint32_t)(hv.z == hi) << 2) | ((uint32_t)(hv.w == hi) << 3);
+        }
+        more = cnt > 4;
+        return eq & ((1u << min(cnt, 4u)) - 1u);
+    };
+
+    // ---- probe: chunks of JN_SUB rows, strided over the grid
+    const uint32_t n = bp.S.n_rows;
+    for (uint64_t base = (uint64_t)blockIdx.x * JN_SUB; base < n; base += (uint64_t)gridDim.x * JN_SUB) {
+        uint32_t klo[JN_SPT], khi[JN_SPT], m[JN_SPT];
+#pragma unroll
+        for (int j = 0; j < JN_SPT; ++j) {
+            const uint64_t row = base + (uint64_t)j * JN_THREADS + threadIdx.x;
+            m[j] = 0;
+            klo[j] = khi[j] = 0;
+            if (row < n && src_key<KW>(bp.S, (uint32_t)row, klo[j], khi[j])) {
+                uint32_t b = klo[j] & BMASK;
+                bool     more;
+                do {
+                    m[j] += (uint32_t)__popc(match(b, klo[j], khi[j], more));
+                    b = (b + 1) & BMASK;
+                } while (more);
+            }
+        }
+        // output offsets: wave prefix (ballot when every lane has <= 1 match), one global
+        // reservation per chunk
+        uint32_t pre[JN_SPT], wave_total = 0;
+#pragma unroll
+        for (int j = 0; j < JN_SPT; ++j) {
+            uint32_t tot;
+            if (__ballot(m[j] > 1) == 0) {
+                uint64_t mk = __ballot(m[j] == 1);
+                pre[j] = lane_prefix(mk);
+                tot = (uint32_t)__popcll(mk);
+            } else {
+                uint32_t incl = m[j];
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    uint32_t t = __shfl_up(incl, off);
+                    if (lane >= (uint32_t)off) incl += t;
+                }
+                pre[j] = incl - m[j];
+                tot = __shfl(incl, 63);
+            }
+            pre[j] += wave_total;
+            wave_total += tot;
+        }
+        if (lane == 0) s_wtot[wid] = wave_total;
+        lds_barrier();
+        if (threadIdx.x == 0) {
+            uint32_t tot = 0;
+            for (int w = 0; w < JN_THREADS / 64; ++w) tot += s_wtot[w];
+            s_obase = tot ? atomicAdd(bp.out_cursor, (unsigned long long)tot) : 0ull;
+        }
+        lds_barrier();
+        const uint64_t gbase = s_obase;
+        uint64_t       obase = gbase;
+        uint32_t       block_total = 0;
+        for (uint32_t w = 0; w < JN_THREADS / 64; ++w) {
+            uint32_t t = s_wtot[w];
+            if (w < wid) obase += t;
+            block_total += t;
+        }
+        // rows beyond the stream capacity are counted but not written (the host re-runs the
+        // join with exact-size buffers)
+        if (gbase + block_total <= bp.out_cap) {
+#pragma unroll
+            for (int j = 0; j < JN_SPT; ++j) {
+                if (m[j] == 0) continue;
+                const uint32_t srow = (uint32_t)(base + (uint64_t)j * JN_THREADS + threadIdx.x);
+                uint64_t       row = obase + pre[j];
+                uint32_t       k0, k1 = 0;
+                if (KW == 1) {
+                    k0 = unfmix32(klo[j]);
+                } else {
+                    uint64_t k64 = unfmix64((uint64_t)klo[j] | ((uint64_t)khi[j] << 32));
+                    k0 = (uint32_t)k64;
+                    k1 = (uint32_t)(k64 >> 32);
+                }
+                uint32_t p0, p1;
+                src_carry<CWS>(bp.S, srow, p0, p1);
+                uint32_t b = klo[j] & BMASK;
+                bool     more;
+                do {
+                    uint32_t eq = match(b, klo[j], khi[j], more);
+                    while (eq) {
+                        const uint32_t slot = b * 4 + (uint32_t)__builtin_ctz(eq);
+                        eq &= eq - 1;
+                        uint32_t b0, b1;
+                        src_carry<CWR>(bp.R, t_w[KW][slot], b0, b1);
+                        stream_store(bp.key, row, k0, k1);
+                        if constexpr (CWR >= 1) stream_store(bp.bc, row, b0, b1);
+                        if constexpr (CWS >= 1) stream_store(bp.pc, row, p0, p1);
+                        ++row;
+                    }
+                    b = (b + 1) & BMASK;
+                } while (more);
+            }
+        }
+        lds_barrier();  // s_wtot / s_obase are reused by the next chunk
+    }
+}
+
 // ================================================================== K7 gather
 // Late materialisation: out[i] = column[idx[i]] (reference counterpart: the
 // per-row `out.push_back(lrow[ci])`, src/execute.cpp:236-242).
@@ -1656,6 +1844,37 @@ void launch_join(const Launch& L, int key_words, int cw_build, int cw_probe, con
     case 220: join_t<2, 2, 0>(L, jp, grid); break;
     case 221: join_t<2, 2, 1>(L, jp, grid); break;
     case 222: join_t<2, 2, 2>(L, jp, grid); break;
+    default: break;
+    }
+}
+
+template <int KW, int CWR, int CWS>
+static void join_bcast_t(const Launch& L, const BcastParams& bp, uint32_t grid) {
+    RJ_KLAUNCH(L, "join_broadcast", (k_join_bcast<KW, CWR, CWS>), grid, JN_THREADS, bp);
+}
+
+void launch_join_bcast(const Launch& L, int key_words, int cw_build, int cw_probe,
+                       const BcastParams& bp, uint32_t grid) {
+    if (!grid) return;
+    switch (key_words * 100 + cw_build * 10 + cw_probe) {
+    case 100: join_bcast_t<1, 0, 0>(L, bp, grid); break;
+    case 101: join_bcast_t<1, 0, 1>(L, bp, grid); break;
+    case 102: join_bcast_t<1, 0, 2>(L, bp, grid); break;
+    case 110: join_bcast_t<1, 1, 0>(L, bp, grid); break;
+    case 111: join_bcast_t<1, 1, 1>(L, bp, grid); break;
+    case 112: join_bcast_t<1, 1, 2>(L, bp, grid); break;
+    case 120: join_bcast_t<1, 2, 0>(L, bp, grid); break;
+    case 121: join_bcast_t<1, 2, 1>(L, bp, grid); break;
+    case 122: join_bcast_t<1, 2, 2>(L, bp, grid); break;
+    case 200: join_bcast_t<2, 0, 0>(L, bp, grid); break;
+    case 201: join_bcast_t<2, 0, 1>(L, bp, grid); break;
+    case 202: join_bcast_t<2, 0, 2>(L, bp, grid); break;
+    case 210: join_bcast_t<2, 1, 0>(L, bp, grid); break;
+    case 211: join_bcast_t<2, 1, 1>(L, bp, grid); break;
+    case 212: join_bcast_t<2, 1, 2>(L, bp, grid); break;
+    case 220: join_bcast_t<2, 2, 0>(L, bp, grid); break;
+    case 221: join_bcast_t<2, 2, 1>(L, bp, grid); break;
+    case 222: join_bcast_t<2, 2, 2>(L, bp, grid); break;
     default: break;
     }
 }

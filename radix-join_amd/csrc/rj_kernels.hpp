@@ -70,6 +70,11 @@ void launch_heavy_tasks(const Launch& L, const uint32_t* offR, const uint32_t* o
 void launch_join(const Launch& L, int key_words, int cw_build, int cw_probe, const JoinParams& jp,
                  uint32_t grid);
 
+// Broadcast join: build side of at most JN_RMAX rows, no partitioning; `grid` workgroups stride
+// over the probe rows in chunks of JN_SUB.
+void launch_join_bcast(const Launch& L, int key_words, int cw_build, int cw_probe,
+                       const BcastParams& bp, uint32_t grid);
+
 // ---- materialise (replaces the per-row output copy, reference src/execute.cpp:236-242,
 //      and Table::to_columnar, src/build_table.cpp:456-594)
 void launch_gather(const Launch& L, const ColRef& src, const uint32_t* idx, uint64_t n,

@@ -127,10 +127,11 @@ def test_random_plan(ctx, seed):
 
 
 # The same random plans under forced radix plans: small inputs never reach the multi-pass
-# partitioner on their own.  11 bits = two passes with the fine (two-digit) histogram,
+# partitioner on their own (their build sides take the broadcast join).  3 bits = one pass,
+# 11 bits = two passes with the fine (two-digit) histogram,
 # 17 bits = two passes above its LDS limit, 20 bits = three passes; nearly all partitions
 # are empty or hold a single tuple.
-@pytest.mark.parametrize("bits", [11, 17, 20])
+@pytest.mark.parametrize("bits", [3, 11, 17, 20])
 @pytest.mark.parametrize("seed", range(_FIRST, _FIRST + min(_COUNT, 40)))
 def test_random_plan_forced_radix(seed, bits):
     p = random_plan(seed)
