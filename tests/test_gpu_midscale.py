@@ -82,3 +82,40 @@ def test_midscale_random_join(ctx, seed):
     assert got.num_rows == want.num_rows
     assert want.num_rows > 0
     assert pl.table_digest(got) == pl.table_digest(want)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_midscale_broadcast_join(ctx, seed):
+    """Build sides of 1..4096 rows (not partitioned: k_join_bcast) against 1-4 M probe rows:
+    duplicate build keys (up to the whole build side on ONE key), NULL keys on both sides,
+    every key type, nullable and wide payloads, probe keys that mostly miss."""
+    rng = np.random.default_rng(2000 + seed)
+    kt = [pl.INT32, pl.INT64, pl.FP64, pl.INT32][seed % 4]
+    nb = [1, 3, 64, 500, 2048, 4096, 4095, 4096][seed]
+    npr = int(rng.integers(1_000_000, 4_000_000))
+    domain = 1 if seed == 7 else max(1, int(nb * rng.uniform(0.3, 3.0)))  # seed 7: one key, 4096 copies
+    bk = keys(rng, nb, domain, kt)
+    # most probe keys miss unless the domain is tiny; keep the output below ~2 |probe|
+    pdomain = domain if seed != 7 else 5000
+    pk = keys(rng, npr, max(pdomain, 1) * (1 if nb * 2 >= domain and seed != 7 else 1), kt)
+    if seed == 7:
+        pk = keys(rng, npr, 5000, kt)  # 1/5000 of the probe rows hit the 4096 copies
+    elif domain > 0 and nb / domain > 2:  # several copies per build key: thin the hits out
+        pk = keys(rng, npr, domain * 8, kt)
+    bkey = (kt, bk, rng.random(nb) >= 0.1) if seed % 2 else (kt, bk)
+    pkey = (kt, pk, rng.random(npr) >= 0.05) if seed % 3 == 0 else (kt, pk)
+    bcols = [bkey, column(rng, nb, pl.INT64 if seed % 2 else pl.INT32, 0.2 if seed % 4 == 2 else 0.0)]
+    pcols = [pkey, column(rng, npr, pl.INT32, 0.0)] + ([column(rng, npr, pl.FP64, 0.1)] if seed % 2 else [])
+    bt, pt = pl.make_table(bcols), pl.make_table(pcols)
+    p = pl.Plan()
+    b = p.new_scan_node(0, [(i, c[0]) for i, c in enumerate(bcols)])
+    s = p.new_scan_node(1, [(i, c[0]) for i, c in enumerate(pcols)])
+    both = [c[0] for c in pcols] + [c[0] for c in bcols]
+    j = p.new_join_node(False, s, b, 0, 0, [(i, t) for i, t in enumerate(both)])
+    p.new_input(bt)
+    p.new_input(pt)
+    p.root = j
+    want = _oracle.execute(p)
+    got = capi.execute(p, ctx)
+    assert got.num_rows == want.num_rows
+    assert pl.table_digest(got) == pl.table_digest(want)
