@@ -5,6 +5,8 @@
 // VARCHAR slabs.  Spawning threads per 32 MiB chunk cost as much as the copy itself for the
 // small JOB tables, so the workers are started once per process and parked on a condition
 // variable between jobs.
+#include <immintrin.h>
+
 #include <atomic>
 #include <condition_variable>
 #include <exception>
@@ -102,6 +104,36 @@ class HostPool {
 };
 
 }  // namespace
+
+// One 8 KiB page, destination not read first: a plain memcpy into memory that is not in cache
+// costs a read-for-ownership of every destination line on top of the source read and the
+// write-back; streaming stores skip it, which is a third of the host memory traffic of the
+// gather into pinned staging.  (The other direction, pinned staging -> the caller's result
+// pages, measured slower with streaming stores and stays a memcpy.)
+__attribute__((target("avx2"))) static void copy_page_avx2(void* dst, const void* src) {
+    const __m256i* s = static_cast<const __m256i*>(src);
+    __m256i*       d = static_cast<__m256i*>(dst);
+    for (size_t i = 0; i < PAGE_BYTES / 32; i += 4) {
+        __m256i a = _mm256_loadu_si256(s + i), b = _mm256_loadu_si256(s + i + 1);
+        __m256i c = _mm256_loadu_si256(s + i + 2), e = _mm256_loadu_si256(s + i + 3);
+        _mm256_stream_si256(d + i, a);
+        _mm256_stream_si256(d + i + 1, b);
+        _mm256_stream_si256(d + i + 2, c);
+        _mm256_stream_si256(d + i + 3, e);
+    }
+}
+
+void copy_page(void* dst, const void* src) {
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    // streaming stores need a 32-byte aligned destination (pinned staging is; a caller's Page
+    // is only guaranteed alignas(8), reference include/plan.h:54)
+    if (avx2 && (reinterpret_cast<uintptr_t>(dst) & 31u) == 0)
+        copy_page_avx2(dst, src);
+    else
+        memcpy(dst, src, PAGE_BYTES);
+}
+
+void copy_pages_fence() { _mm_sfence(); }
 
 void parallel_for(size_t n, size_t grain, const std::function<void(size_t, size_t)>& fn) {
     // never destroyed: the parked workers must not outlive their mutexes at process exit

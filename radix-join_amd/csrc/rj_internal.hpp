@@ -237,6 +237,11 @@ void   result_copy_pages(Result* r, uint64_t col, void* const* dst, uint64_t n_d
 // worker threads plus the caller; the first exception thrown by fn is rethrown here.
 void parallel_for(size_t n, size_t grain, const std::function<void(size_t, size_t)>& fn);
 
+// One 8 KiB page with streaming stores when the destination is 32-byte aligned (else memcpy);
+// copy_pages_fence() orders a thread's streaming stores before it reports its range done.
+void copy_page(void* dst, const void* src);
+void copy_pages_fence();
+
 // rj_varchar.cpp (host only)
 // Page directory of a VARCHAR column: row_base[p] = rows before page p, row_base[n_pages] =
 // rows the pages hold.  Throws "row_idx" if they hold more than num_rows.
