@@ -106,11 +106,14 @@ constexpr int      JN_SUB     = JN_THREADS * JN_SPT;   // probe tuples per outpu
 constexpr int      JN_CAP     = RJ_JN_CAP;             // LDS table slots (power of two)
 constexpr int      JN_RMAX    = JN_CAP / 2;            // build tuples per table (load <= 50 %)
 constexpr int      JN_RPT     = (JN_RMAX + JN_THREADS - 1) / JN_THREADS;  // build tuples per thread
+// Threads of a join workgroup: tables of 3+ word arrays only fit once per CU, that one workgroup
+// then brings all 16 waves itself.
+constexpr int jn_threads(int table_words) { return table_words >= 3 ? 2 * JN_THREADS : JN_THREADS; }
 // __launch_bounds__ "waves per SIMD" for the join: as many workgroups per CU as the LDS
 // table (table_words arrays of JN_CAP words) allows, times threads / 256, capped at 8
 constexpr int jn_min_waves(int table_words) {
     int blocks = (160 * 1024) / (JN_CAP * 4 * table_words + JN_CAP + 1024);
-    int w = blocks * JN_THREADS / 256;
+    int w = blocks * jn_threads(table_words) / 256;
     return w > 8 ? 8 : (w < 1 ? 1 : w);
 }
 static_assert(JN_RPT % 4 == 0 && JN_SPT % 4 == 0, "tuples are loaded as 16-byte vectors");

@@ -901,13 +901,19 @@ enum { OM_GENERIC = 0, OM_PAGED32 = 1, OM_DENSE32 = 2 };
 
 // PK: bit 0 = the build side, bit 1 = the probe side is a packed {hashed key, carry} array
 template <int KW, int CWR, int CWS, int OM, int PK>
-__global__ __launch_bounds__(JN_THREADS, jn_min_waves(KW + (CWR == 2 ? 1 : CWR))) void k_join(JoinParams jp) {
-    // A two-word build carry is NOT kept in the LDS table: the table then stores the build
-    // tuple's position instead and the carry words are fetched from the partitioned build
-    // arrays on emit (the partition's chunk was just streamed, so they come from L2).  That
-    // keeps the table at two arrays (two workgroups per CU) for INT64 payloads.
-    constexpr bool     IND = CWR == 2;
-    constexpr int      RW = KW + (IND ? 1 : CWR);  // LDS table arrays (one per word)
+__global__ __launch_bounds__(jn_threads(KW + CWR), jn_min_waves(KW + CWR)) void k_join(JoinParams jp) {
+    // Tables of three or four word arrays (64-bit keys, two-word build carries) leave room for
+    // ONE workgroup per CU; it then runs 1024 threads, so the CU holds the same 16 waves as with
+    // two 512-thread workgroups.  (Fetching wide build carries from the partitioned arrays on
+    // emit instead — a two-array table — cost 7 of 17 ms at 1 B rows: 2 random 4-byte reads per
+    // match are bound by the request rate of the vector memory path.)
+    constexpr int      TH = jn_threads(KW + CWR);
+    constexpr int      RPT = (JN_RMAX + TH - 1) / TH;  // build tuples per thread
+    constexpr int      SPT = JN_SUB / TH;          // probe tuples per thread per sub-chunk
+    constexpr int      SUB = JN_SUB;
+    static_assert(RPT % 4 == 0 && SPT % 4 == 0, "tuples are loaded as 16-byte vectors");
+    constexpr bool     IND = false;
+    constexpr int      RW = KW + CWR;  // LDS table arrays (one per word)
     constexpr int      SW = KW + CWS;
     // Bucketised table: JN_CAP slots = JN_CAP/4 buckets of 4 consecutive slots.  A probe
     // reads a whole bucket with ONE 16-byte LDS read and compares in registers, an insert
@@ -916,7 +922,7 @@ __global__ __launch_bounds__(JN_THREADS, jn_min_waves(KW + (CWR == 2 ? 1 : CWR))
     // A full bucket (4th slot used) sends probe and insert on to the next bucket.
     __shared__ __attribute__((aligned(16))) uint32_t t_w[RW][JN_CAP];
     __shared__ __attribute__((aligned(16))) uint32_t t_cnt[JN_CAP / 4];
-    __shared__ uint32_t s_wtot[JN_THREADS / 64];
+    __shared__ uint32_t s_wtot[TH / 64];
     __shared__ unsigned long long s_obase;
 
     const uint32_t     lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
@@ -957,15 +963,15 @@ __global__ __launch_bounds__(JN_THREADS, jn_min_waves(KW + (CWR == 2 ? 1 : CWR))
         return t;
     };
 
-    // item j of a thread is element ((j/4)*JN_THREADS + tid)*4 + j%4: four consecutive
+    // item j of a thread is element ((j/4)*TH + tid)*4 + j%4: four consecutive
     // tuples per 16-byte load
-    uint32_t rw[JN_RPT][RW];
-    uint32_t sw[JN_SPT][SW];
+    uint32_t rw[RPT][RW];
+    uint32_t sw[SPT][SW];
     // item j of a thread holds element item_index(j): four consecutive tuples per 16-byte load
     // of a word array, two consecutive {key, carry} pairs per load of a packed array
     auto item_index = [&](int j, bool packed) -> uint32_t {
-        return packed ? ((j / 2) * JN_THREADS + threadIdx.x) * 2 + (j % 2)
-                      : ((j / 4) * JN_THREADS + threadIdx.x) * 4 + (j % 4);
+        return packed ? ((j / 2) * TH + threadIdx.x) * 2 + (j % 2)
+                      : ((j / 4) * TH + threadIdx.x) * 4 + (j % 4);
     };
     constexpr bool packR = (PK & 1) != 0, packS = (PK & 2) != 0;
     static_assert(!packR || (KW == 1 && CWR == 1), "packed build side: key + one carry word");
@@ -976,8 +982,8 @@ __global__ __launch_bounds__(JN_THREADS, jn_min_waves(KW + (CWR == 2 ? 1 : CWR))
             {
                 const uint2* rp = reinterpret_cast<const uint2*>(jp.R.w[0]) + rc;
 #pragma unroll
-                for (int v = 0; v < JN_RPT / 2; ++v) {
-                    const uint32_t i0 = (v * JN_THREADS + threadIdx.x) * 2;
+                for (int v = 0; v < RPT / 2; ++v) {
+                    const uint32_t i0 = (v * TH + threadIdx.x) * 2;
                     if (i0 + 1 < rn) {
                         u32x4a x = *reinterpret_cast<const u32x4a*>(rp + i0);
                         rw[2 * v][0] = x[0];
@@ -997,8 +1003,8 @@ __global__ __launch_bounds__(JN_THREADS, jn_min_waves(KW + (CWR == 2 ? 1 : CWR))
             }
         }
 #pragma unroll
-        for (int v = 0; v < JN_RPT / 4; ++v) {
-            const uint32_t i0 = (v * JN_THREADS + threadIdx.x) * 4;
+        for (int v = 0; v < RPT / 4; ++v) {
+            const uint32_t i0 = (v * TH + threadIdx.x) * 4;
             if (i0 + 3 < rn) {
 #pragma unroll
                 for (int a = 0; a < LW; ++a) {
@@ -1024,8 +1030,8 @@ __global__ __launch_bounds__(JN_THREADS, jn_min_waves(KW + (CWR == 2 ? 1 : CWR))
             {
                 const uint2* sp = reinterpret_cast<const uint2*>(jp.S.w[0]) + sc;
 #pragma unroll
-                for (int v = 0; v < JN_SPT / 2; ++v) {
-                    const uint32_t i0 = (v * JN_THREADS + threadIdx.x) * 2;
+                for (int v = 0; v < SPT / 2; ++v) {
+                    const uint32_t i0 = (v * TH + threadIdx.x) * 2;
                     if (i0 + 1 < sn) {
                         u32x4a x = *reinterpret_cast<const u32x4a*>(sp + i0);
                         sw[2 * v][0] = x[0];
@@ -1045,8 +1051,8 @@ __global__ __launch_bounds__(JN_THREADS, jn_min_waves(KW + (CWR == 2 ? 1 : CWR))
             }
         }
 #pragma unroll
-        for (int v = 0; v < JN_SPT / 4; ++v) {
-            const uint32_t i0 = (v * JN_THREADS + threadIdx.x) * 4;
+        for (int v = 0; v < SPT / 4; ++v) {
+            const uint32_t i0 = (v * TH + threadIdx.x) * 4;
             if (i0 + 3 < sn) {
 #pragma unroll
                 for (int a = 0; a < SW; ++a) {
@@ -1098,7 +1104,7 @@ __global__ __launch_bounds__(JN_THREADS, jn_min_waves(KW + (CWR == 2 ? 1 : CWR))
             continue;
         }
         if (!haveR) load_build(cur.rbeg, min((uint32_t)JN_RMAX, cur.rend - cur.rbeg));
-        if (!haveS) load_probe(cur.sbeg, min((uint32_t)JN_SUB, cur.send - cur.sbeg));
+        if (!haveS) load_probe(cur.sbeg, min((uint32_t)SUB, cur.send - cur.sbeg));
         uint32_t sw_pos = cur.sbeg;  // which probe sub-chunk sw holds
         RJ_STAMP(0);  // loads issued
 
@@ -1123,16 +1129,16 @@ __global__ __launch_bounds__(JN_THREADS, jn_min_waves(KW + (CWR == 2 ? 1 : CWR))
             {  // clear the key array, 16 bytes per store
                 const uint4 e4 = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
                 uint4*      t4 = reinterpret_cast<uint4*>(&t_w[0][0]);
-                for (uint32_t i = threadIdx.x; i < JN_CAP / 4; i += JN_THREADS) t4[i] = e4;
+                for (uint32_t i = threadIdx.x; i < JN_CAP / 4; i += TH) t4[i] = e4;
                 uint4* c4 = reinterpret_cast<uint4*>(&t_cnt[0]);
-                for (uint32_t i = threadIdx.x; i < JN_CAP / 16; i += JN_THREADS)
+                for (uint32_t i = threadIdx.x; i < JN_CAP / 16; i += TH)
                     c4[i] = make_uint4(0, 0, 0, 0);
             }
             lds_barrier();
             RJ_STAMP(1);  // table cleared
             // ---- build
 #pragma unroll
-            for (int j = 0; j < JN_RPT; ++j) {
+            for (int j = 0; j < RPT; ++j) {
                 uint32_t i = item_index(j, packR);
                 if (i < rn) {
                     uint32_t b = (rw[j][0] >> jp.radix_bits) & BMASK;
@@ -1155,17 +1161,17 @@ __global__ __launch_bounds__(JN_THREADS, jn_min_waves(KW + (CWR == 2 ? 1 : CWR))
             if (last_chunk && nxt.active)
                 load_build(nxt.rbeg, min((uint32_t)JN_RMAX, nxt.rend - nxt.rbeg));
 
-            // ---- probe, JN_SUB tuples at a time
-            for (uint32_t sc = cur.sbeg; sc < cur.send; sc += JN_SUB) {
-                const uint32_t sn = min((uint32_t)JN_SUB, cur.send - sc);
+            // ---- probe, SUB tuples at a time
+            for (uint32_t sc = cur.sbeg; sc < cur.send; sc += SUB) {
+                const uint32_t sn = min((uint32_t)SUB, cur.send - sc);
                 if (sw_pos != sc) {
                     load_probe(sc, sn);
                     sw_pos = sc;
                 }
-                uint32_t m[JN_SPT], f[JN_SPT];
+                uint32_t m[SPT], f[SPT];
                 // count matches, remember the first matching slot
 #pragma unroll
-                for (int j = 0; j < JN_SPT; ++j) {
+                for (int j = 0; j < SPT; ++j) {
                     uint32_t i = item_index(j, packS);
                     m[j] = 0;
                     f[j] = 0;
@@ -1192,10 +1198,10 @@ __global__ __launch_bounds__(JN_THREADS, jn_min_waves(KW + (CWR == 2 ? 1 : CWR))
                 RJ_STAMP(3);  // counted
                 // offsets inside the wave: ballot + mbcnt when every lane has <= 1 match
                 // (the PK-FK case), shuffle scan otherwise
-                uint32_t pre[JN_SPT];
+                uint32_t pre[SPT];
                 uint32_t wave_total = 0;
 #pragma unroll
-                for (int j = 0; j < JN_SPT; ++j) {
+                for (int j = 0; j < SPT; ++j) {
                     uint32_t tot;
                     if (__ballot(m[j] > 1) == 0) {
                         uint64_t mk = __ballot(m[j] == 1);
@@ -1219,7 +1225,7 @@ __global__ __launch_bounds__(JN_THREADS, jn_min_waves(KW + (CWR == 2 ? 1 : CWR))
                 RJ_STAMP(4);  // wave prefixes + barrier
                 if (threadIdx.x == 0) {
                     uint32_t tot = 0;
-                    for (int w = 0; w < JN_THREADS / 64; ++w) tot += s_wtot[w];
+                    for (int w = 0; w < TH / 64; ++w) tot += s_wtot[w];
                     s_obase = tot ? atomicAdd(jp.out_cursor, (unsigned long long)tot) : 0ull;
                 }
                 lds_barrier();
@@ -1227,7 +1233,7 @@ __global__ __launch_bounds__(JN_THREADS, jn_min_waves(KW + (CWR == 2 ? 1 : CWR))
                 const uint64_t gbase = s_obase;
                 uint64_t       obase = gbase;
                 uint32_t       block_total = 0;
-                for (uint32_t w = 0; w < JN_THREADS / 64; ++w) {
+                for (uint32_t w = 0; w < TH / 64; ++w) {
                     uint32_t t = s_wtot[w];
                     if (w < wid) obase += t;
                     block_total += t;
@@ -1238,9 +1244,9 @@ __global__ __launch_bounds__(JN_THREADS, jn_min_waves(KW + (CWR == 2 ? 1 : CWR))
                 if (fits) {
                     // the build carry of a tuple's FIRST match sits at the remembered slot
                     // f[j]: issue those reads for all tuples before the first store
-                    uint32_t c0[JN_SPT], c1[JN_SPT];
+                    uint32_t c0[SPT], c1[SPT];
 #pragma unroll
-                    for (int j = 0; j < JN_SPT; ++j) {
+                    for (int j = 0; j < SPT; ++j) {
                         c0[j] = 0;
                         c1[j] = 0;
                         if constexpr (IND) {
@@ -1251,10 +1257,11 @@ __global__ __launch_bounds__(JN_THREADS, jn_min_waves(KW + (CWR == 2 ? 1 : CWR))
                             }
                         } else {
                             if constexpr (CWR >= 1) c0[j] = m[j] ? t_w[KW][f[j]] : 0u;
+                            if constexpr (CWR == 2) c1[j] = m[j] ? t_w[KW + 1][f[j]] : 0u;
                         }
                     }
 #pragma unroll
-                    for (int j = 0; j < JN_SPT; ++j) {
+                    for (int j = 0; j < SPT; ++j) {
                         if (m[j] == 0) continue;
                         uint64_t row = obase + pre[j];
                         uint32_t klo, khi = 0;
@@ -1284,6 +1291,7 @@ __global__ __launch_bounds__(JN_THREADS, jn_min_waves(KW + (CWR == 2 ? 1 : CWR))
                                     b1 = jp.R.w[KW + 1][pos];
                                 } else if constexpr (CWR >= 1) {
                                     b0 = t_w[KW][slot];
+                                    if constexpr (CWR == 2) b1 = t_w[KW + 1][slot];
                                 }
                                 emit_row(row, klo, khi, b0, b1, p0, p1);
                                 --left;
@@ -1298,7 +1306,7 @@ __global__ __launch_bounds__(JN_THREADS, jn_min_waves(KW + (CWR == 2 ? 1 : CWR))
             lds_barrier();  // table is cleared for the next build chunk
         }
         // sw is dead now: start the next partition's probe loads behind its table build
-        if (nxt.active) load_probe(nxt.sbeg, min((uint32_t)JN_SUB, nxt.send - nxt.sbeg));
+        if (nxt.active) load_probe(nxt.sbeg, min((uint32_t)SUB, nxt.send - nxt.sbeg));
         haveR = haveS = nxt.active;
         cur = nxt;
     }
@@ -1794,15 +1802,15 @@ static void join_pk(const Launch& L, const JoinParams& jp, uint32_t grid) {
     }
     if constexpr (KW == 1 && CWR <= 1 && CWS <= 1) {
         if (om == OM_PAGED32) {
-            RJ_KLAUNCH(L, name, (k_join<KW, CWR, CWS, OM_PAGED32, PK>), grid, JN_THREADS, jp);
+            RJ_KLAUNCH(L, name, (k_join<KW, CWR, CWS, OM_PAGED32, PK>), grid, jn_threads(KW + CWR), jp);
             return;
         }
         if (om == OM_DENSE32) {
-            RJ_KLAUNCH(L, name, (k_join<KW, CWR, CWS, OM_DENSE32, PK>), grid, JN_THREADS, jp);
+            RJ_KLAUNCH(L, name, (k_join<KW, CWR, CWS, OM_DENSE32, PK>), grid, jn_threads(KW + CWR), jp);
             return;
         }
     }
-    RJ_KLAUNCH(L, name, (k_join<KW, CWR, CWS, OM_GENERIC, PK>), grid, JN_THREADS, jp);
+    RJ_KLAUNCH(L, name, (k_join<KW, CWR, CWS, OM_GENERIC, PK>), grid, jn_threads(KW + CWR), jp);
 }
 
 // the packed variants exist only for the shapes that can be packed
