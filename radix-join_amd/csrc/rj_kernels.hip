@@ -912,7 +912,6 @@ __global__ __launch_bounds__(jn_threads(KW + CWR), jn_min_waves(KW + CWR)) void 
     constexpr int      SPT = JN_SUB / TH;          // probe tuples per thread per sub-chunk
     constexpr int      SUB = JN_SUB;
     static_assert(RPT % 4 == 0 && SPT % 4 == 0, "tuples are loaded as 16-byte vectors");
-    constexpr bool     IND = false;
     constexpr int      RW = KW + CWR;  // LDS table arrays (one per word)
     constexpr int      SW = KW + CWS;
     // Bucketised table: JN_CAP slots = JN_CAP/4 buckets of 4 consecutive slots.  A probe
@@ -977,7 +976,7 @@ __global__ __launch_bounds__(jn_threads(KW + CWR), jn_min_waves(KW + CWR)) void 
     static_assert(!packR || (KW == 1 && CWR == 1), "packed build side: key + one carry word");
     static_assert(!packS || (KW == 1 && CWS == 1), "packed probe side: key + one carry word");
     auto load_build = [&](uint32_t rc, uint32_t rn) {
-        constexpr int LW = IND ? KW : RW;  // words actually read from the build arrays
+        constexpr int LW = RW;
         if constexpr (packR) {
             {
                 const uint2* rp = reinterpret_cast<const uint2*>(jp.R.w[0]) + rc;
@@ -1018,10 +1017,6 @@ __global__ __launch_bounds__(jn_threads(KW + CWR), jn_min_waves(KW + CWR)) void 
 #pragma unroll
                     for (int a = 0; a < LW; ++a)
                         rw[4 * v + e][a] = i0 + e < rn ? jp.R.w[a][rc + i0 + e] : 0u;
-            }
-            if constexpr (IND) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) rw[4 * v + e][KW] = rc + i0 + e;  // build position
             }
         }
     };
@@ -1249,16 +1244,8 @@ __global__ __launch_bounds__(jn_threads(KW + CWR), jn_min_waves(KW + CWR)) void 
                     for (int j = 0; j < SPT; ++j) {
                         c0[j] = 0;
                         c1[j] = 0;
-                        if constexpr (IND) {
-                            if (m[j]) {
-                                const uint32_t pos = t_w[KW][f[j]];
-                                c0[j] = jp.R.w[KW][pos];
-                                c1[j] = jp.R.w[KW + 1][pos];
-                            }
-                        } else {
-                            if constexpr (CWR >= 1) c0[j] = m[j] ? t_w[KW][f[j]] : 0u;
-                            if constexpr (CWR == 2) c1[j] = m[j] ? t_w[KW + 1][f[j]] : 0u;
-                        }
+                        if constexpr (CWR >= 1) c0[j] = m[j] ? t_w[KW][f[j]] : 0u;
+                        if constexpr (CWR == 2) c1[j] = m[j] ? t_w[KW + 1][f[j]] : 0u;
                     }
 #pragma unroll
                     for (int j = 0; j < SPT; ++j) {
@@ -1285,14 +1272,8 @@ __global__ __launch_bounds__(jn_threads(KW + CWR), jn_min_waves(KW + CWR)) void 
                             if (eq) {
                                 ++row;
                                 uint32_t b0 = 0, b1 = 0;
-                                if constexpr (IND) {
-                                    const uint32_t pos = t_w[KW][slot];
-                                    b0 = jp.R.w[KW][pos];
-                                    b1 = jp.R.w[KW + 1][pos];
-                                } else if constexpr (CWR >= 1) {
-                                    b0 = t_w[KW][slot];
-                                    if constexpr (CWR == 2) b1 = t_w[KW + 1][slot];
-                                }
+                                if constexpr (CWR >= 1) b0 = t_w[KW][slot];
+                                if constexpr (CWR == 2) b1 = t_w[KW + 1][slot];
                                 emit_row(row, klo, khi, b0, b1, p0, p1);
                                 --left;
                             }
