@@ -319,7 +319,10 @@ class Exec {
         BufP  A[MAX_WORDS], B[MAX_WORDS];
         Words wa{}, wb{};
         for (int a = 0; a < (P.packed ? 1 : P.NW); ++a) {
-            const uint64_t wbytes = P.packed ? 8 : 4;
+            // a two-word carry is ONE array of 8-byte pairs (at word KW), key + one carry word
+            // one array of pairs altogether (packed)
+            if (CW == 2 && a == KW + 1) continue;
+            const uint64_t wbytes = (P.packed || (CW == 2 && a == KW)) ? 8 : 4;
             if (external) {
                 wa.w[a] = external->w[a];
                 continue;
@@ -406,7 +409,7 @@ class Exec {
                 } else if (p == 0) {
                     launch_pass_scatter_src(L, src, KW, CW, pp, n_groups, nxt);
                 } else {
-                    launch_pass_scatter_dense(L, cur, P.NW, pp, n_groups, nxt);
+                    launch_pass_scatter_dense(L, cur, P.NW, CW == 2 ? KW : -1, pp, n_groups, nxt);
                 }
                 seg_off = off;
                 nseg = (uint32_t)bins;

@@ -264,7 +264,10 @@ __global__ __launch_bounds__(PT_MAXF) void k_scan_segments(const uint32_t* hist,
 // decisions (column kind, validity array present, carry mode) are taken once per tile, so
 // the compiler can issue the whole tile's loads back to back behind a single wait.  The
 // returned bit mask says which items hold a tuple.
-struct DenseLoader {
+// PAIR >= 0: in.w[PAIR] is an array of 8-byte {word PAIR, word PAIR+1} pairs (a two-word carry)
+template <int PAIR>
+struct DenseLoaderT {
+    static constexpr int pair = PAIR;
     Words in;
     __device__ __forceinline__ uint32_t key_tile(uint32_t base, uint32_t end,
                                                  uint32_t (&hk)[PT_ITEMS]) const {
@@ -296,9 +299,25 @@ struct DenseLoader {
                 const uint32_t i0 = base + (v * PT_THREADS + threadIdx.x) * 4;
 #pragma unroll
                 for (int a = 0; a < NW; ++a) {
-                    u32x4a x = *reinterpret_cast<const u32x4a*>(in.w[a] + i0);
+                    if (a == pair) {  // four consecutive pairs = two 16-byte loads
+                        const uint32_t* pp2 = in.w[a] + (size_t)i0 * 2;
+                        u32x4a x = *reinterpret_cast<const u32x4a*>(pp2);
+                        u32x4a y = *reinterpret_cast<const u32x4a*>(pp2 + 4);
+                        if constexpr (NW >= 2) {
+                            w[4 * v + 0][a] = x[0];
+                            w[4 * v + 0][a + 1 < NW ? a + 1 : a] = x[1];
+                            w[4 * v + 1][a] = x[2];
+                            w[4 * v + 1][a + 1 < NW ? a + 1 : a] = x[3];
+                            w[4 * v + 2][a] = y[0];
+                            w[4 * v + 2][a + 1 < NW ? a + 1 : a] = y[1];
+                            w[4 * v + 3][a] = y[2];
+                            w[4 * v + 3][a + 1 < NW ? a + 1 : a] = y[3];
+                        }
+                    } else if (a != pair + 1 || pair < 0) {
+                        u32x4a x = *reinterpret_cast<const u32x4a*>(in.w[a] + i0);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) w[4 * v + e][a] = x[e];
+                        for (int e = 0; e < 4; ++e) w[4 * v + e][a] = x[e];
+                    }
                 }
             }
             return (1u << PT_ITEMS) - 1u;
@@ -309,12 +328,22 @@ struct DenseLoader {
             uint32_t i = base + j * PT_THREADS + threadIdx.x;
             uint32_t ic = min(i, end - 1u);
 #pragma unroll
-            for (int a = 0; a < NW; ++a) w[j][a] = in.w[a][ic];
+            for (int a = 0; a < NW; ++a) {
+                if (a == pair) {
+                    const uint2 t = reinterpret_cast<const uint2*>(in.w[a])[ic];
+                    w[j][a] = t.x;
+                    w[j][a + 1 < NW ? a + 1 : a] = t.y;
+                } else if (a != pair + 1 || pair < 0) {
+                    w[j][a] = in.w[a][ic];
+                }
+            }
             ok |= (uint32_t)(i < end) << j;
         }
         return ok;
     }
 };
+
+using DenseLoader = DenseLoaderT<-1>;
 
 // Partitioned tuples of ONE key word + ONE carry word can also be kept packed: an array of
 // 8-byte {hashed key, carry} pairs instead of two word arrays (see k_pass_scatter_packed).
@@ -688,9 +717,13 @@ __global__ __launch_bounds__(PT_MAXF) void k_scan_fine(const uint32_t* fine, uin
 //      (software write-combining: HBM sees contiguous runs, not 4-byte scatters).
 // Every tile reserves its output ranges with one atomic per digit (cursor = start of the
 // digit's partition, from the scanned histogram).
-template <int NW, class Loader>
+// PAIR >= 0: words PAIR and PAIR+1 (a two-word carry) are written as 8-byte pairs into ONE array,
+// out.w[PAIR] — one output stream and one staging round less than two word arrays.
+template <int NW, class Loader, int PAIR>
 __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassParams pp, Words out) {
-    __shared__ uint32_t s_stage[PT_TILE];
+    static_assert(PAIR < 0 || (PAIR >= 1 && PAIR + 1 < NW), "pair = two carry words behind the key");
+    __shared__ uint2    s_stage2[PT_TILE];  // 128 KiB: a word array uses the first half
+    uint32_t* const     s_stage = reinterpret_cast<uint32_t*>(s_stage2);
     __shared__ uint32_t s_cnt[PT_MAXF];
     __shared__ uint32_t s_base[PT_MAXF];
     __shared__ uint32_t s_delta[PT_MAXF];
@@ -759,6 +792,24 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassPara
         lds_barrier();
 #pragma unroll
         for (int a = 1; a < NW; ++a) {
+            if constexpr (PAIR >= 0) {
+                if (a == PAIR + 1) continue;  // went out with word PAIR
+                if (a == PAIR) {
+#pragma unroll
+                    for (int j = 0; j < PT_ITEMS; ++j)
+                        if (dr[j] != 0xffffffffu)
+                            s_stage2[dr[j]] = make_uint2(w[j][a], w[j][a + 1 < NW ? a + 1 : a]);
+                    lds_barrier();
+                    uint2* dst2 = reinterpret_cast<uint2*>(out.w[a]);
+#pragma unroll
+                    for (int k = 0; k < PT_ITEMS; ++k) {
+                        const uint32_t i = k * PT_THREADS + threadIdx.x;
+                        if (i < total) dst2[dest[k]] = s_stage2[i];
+                    }
+                    lds_barrier();
+                    continue;
+                }
+            }
 #pragma unroll
             for (int j = 0; j < PT_ITEMS; ++j)
                 if (dr[j] != 0xffffffffu) s_stage[dr[j]] = w[j][a];
@@ -1001,22 +1052,42 @@ __global__ __launch_bounds__(jn_threads(KW + CWR), jn_min_waves(KW + CWR)) void 
                 return;
             }
         }
+        constexpr int NA = CWR == 2 ? KW : LW;  // plain word arrays; a two-word carry is a pair array
 #pragma unroll
         for (int v = 0; v < RPT / 4; ++v) {
             const uint32_t i0 = (v * TH + threadIdx.x) * 4;
             if (i0 + 3 < rn) {
 #pragma unroll
-                for (int a = 0; a < LW; ++a) {
+                for (int a = 0; a < NA; ++a) {
                     u32x4a x = *reinterpret_cast<const u32x4a*>(jp.R.w[a] + rc + i0);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) rw[4 * v + e][a] = x[e];
                 }
+                if constexpr (CWR == 2) {
+                    const uint32_t* p2 = jp.R.w[KW] + ((size_t)rc + i0) * 2;
+                    u32x4a x = *reinterpret_cast<const u32x4a*>(p2), y = *reinterpret_cast<const u32x4a*>(p2 + 4);
+                    rw[4 * v + 0][KW] = x[0];
+                    rw[4 * v + 0][KW + 1] = x[1];
+                    rw[4 * v + 1][KW] = x[2];
+                    rw[4 * v + 1][KW + 1] = x[3];
+                    rw[4 * v + 2][KW] = y[0];
+                    rw[4 * v + 2][KW + 1] = y[1];
+                    rw[4 * v + 3][KW] = y[2];
+                    rw[4 * v + 3][KW + 1] = y[3];
+                }
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 4; ++e) {
 #pragma unroll
-                    for (int a = 0; a < LW; ++a)
+                    for (int a = 0; a < NA; ++a)
                         rw[4 * v + e][a] = i0 + e < rn ? jp.R.w[a][rc + i0 + e] : 0u;
+                    if constexpr (CWR == 2) {
+                        uint2 t = i0 + e < rn ? reinterpret_cast<const uint2*>(jp.R.w[KW])[rc + i0 + e]
+                                              : make_uint2(0u, 0u);
+                        rw[4 * v + e][KW] = t.x;
+                        rw[4 * v + e][KW + 1] = t.y;
+                    }
+                }
             }
         }
     };
@@ -1045,22 +1116,42 @@ __global__ __launch_bounds__(jn_threads(KW + CWR), jn_min_waves(KW + CWR)) void 
                 return;
             }
         }
+        constexpr int NA = CWS == 2 ? KW : SW;  // plain word arrays; a two-word carry is a pair array
 #pragma unroll
         for (int v = 0; v < SPT / 4; ++v) {
             const uint32_t i0 = (v * TH + threadIdx.x) * 4;
             if (i0 + 3 < sn) {
 #pragma unroll
-                for (int a = 0; a < SW; ++a) {
+                for (int a = 0; a < NA; ++a) {
                     u32x4a x = *reinterpret_cast<const u32x4a*>(jp.S.w[a] + sc + i0);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) sw[4 * v + e][a] = x[e];
                 }
+                if constexpr (CWS == 2) {
+                    const uint32_t* p2 = jp.S.w[KW] + ((size_t)sc + i0) * 2;
+                    u32x4a x = *reinterpret_cast<const u32x4a*>(p2), y = *reinterpret_cast<const u32x4a*>(p2 + 4);
+                    sw[4 * v + 0][KW] = x[0];
+                    sw[4 * v + 0][KW + 1] = x[1];
+                    sw[4 * v + 1][KW] = x[2];
+                    sw[4 * v + 1][KW + 1] = x[3];
+                    sw[4 * v + 2][KW] = y[0];
+                    sw[4 * v + 2][KW + 1] = y[1];
+                    sw[4 * v + 3][KW] = y[2];
+                    sw[4 * v + 3][KW + 1] = y[3];
+                }
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 4; ++e) {
 #pragma unroll
-                    for (int a = 0; a < SW; ++a)
+                    for (int a = 0; a < NA; ++a)
                         sw[4 * v + e][a] = i0 + e < sn ? jp.S.w[a][sc + i0 + e] : 0u;
+                    if constexpr (CWS == 2) {
+                        uint2 t = i0 + e < sn ? reinterpret_cast<const uint2*>(jp.S.w[KW])[sc + i0 + e]
+                                              : make_uint2(0u, 0u);
+                        sw[4 * v + e][KW] = t.x;
+                        sw[4 * v + e][KW + 1] = t.y;
+                    }
+                }
             }
         }
     };
@@ -1689,8 +1780,8 @@ template <int KW, int CW>
 static void scatter_src_t(const Launch& L, const TupleSrc& src, const PassParams& pp,
                           uint32_t n_groups, const Words& out) {
     SrcLoader<KW, CW> ld{src};
-    RJ_KLAUNCH(L, "pass1_scatter", (k_pass_scatter<KW + CW, SrcLoader<KW, CW>>), n_groups,
-               PT_THREADS, ld, pp, out);
+    RJ_KLAUNCH(L, "pass1_scatter", (k_pass_scatter<KW + CW, SrcLoader<KW, CW>, (CW == 2 ? KW : -1)>),
+               n_groups, PT_THREADS, ld, pp, out);
 }
 
 void launch_pass_scatter_src(const Launch& L, const TupleSrc& src, int key_words, int carry_words,
@@ -1714,26 +1805,29 @@ void launch_pass_hist_dense(const Launch& L, const Words& in, const PassParams& 
     RJ_KLAUNCH(L, "pass2_hist", (k_pass_hist<DenseLoader>), n_groups, PT_THREADS, ld, pp);
 }
 
-void launch_pass_scatter_dense(const Launch& L, const Words& in, int n_words, const PassParams& pp,
-                               uint32_t n_groups, const Words& out) {
+void launch_pass_scatter_dense(const Launch& L, const Words& in, int n_words, int pair_word,
+                               const PassParams& pp, uint32_t n_groups, const Words& out) {
     if (!n_groups) return;
-    DenseLoader ld{in};
-    switch (n_words) {
-    case 1:
-        RJ_KLAUNCH(L, "pass2_scatter", (k_pass_scatter<1, DenseLoader>), n_groups, PT_THREADS, ld,
-                   pp, out);
+    switch (n_words * 10 + (pair_word < 0 ? 9 : pair_word)) {
+    case 19:
+        RJ_KLAUNCH(L, "pass2_scatter", (k_pass_scatter<1, DenseLoader, -1>), n_groups, PT_THREADS,
+                   DenseLoader{in}, pp, out);
         break;
-    case 2:
-        RJ_KLAUNCH(L, "pass2_scatter", (k_pass_scatter<2, DenseLoader>), n_groups, PT_THREADS, ld,
-                   pp, out);
+    case 29:
+        RJ_KLAUNCH(L, "pass2_scatter", (k_pass_scatter<2, DenseLoader, -1>), n_groups, PT_THREADS,
+                   DenseLoader{in}, pp, out);
         break;
-    case 3:
-        RJ_KLAUNCH(L, "pass2_scatter", (k_pass_scatter<3, DenseLoader>), n_groups, PT_THREADS, ld,
-                   pp, out);
+    case 39:
+        RJ_KLAUNCH(L, "pass2_scatter", (k_pass_scatter<3, DenseLoader, -1>), n_groups, PT_THREADS,
+                   DenseLoader{in}, pp, out);
         break;
-    case 4:
-        RJ_KLAUNCH(L, "pass2_scatter", (k_pass_scatter<4, DenseLoader>), n_groups, PT_THREADS, ld,
-                   pp, out);
+    case 31:  // key + carry pair
+        RJ_KLAUNCH(L, "pass2_scatter", (k_pass_scatter<3, DenseLoaderT<1>, 1>), n_groups, PT_THREADS,
+                   DenseLoaderT<1>{in}, pp, out);
+        break;
+    case 42:  // two key words + carry pair
+        RJ_KLAUNCH(L, "pass2_scatter", (k_pass_scatter<4, DenseLoaderT<2>, 2>), n_groups, PT_THREADS,
+                   DenseLoaderT<2>{in}, pp, out);
         break;
     default: break;
     }

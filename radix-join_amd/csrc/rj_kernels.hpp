@@ -53,8 +53,10 @@ void launch_pass_scatter_src(const Launch& L, const TupleSrc& src, int key_words
 // Dense pass: re-partition every segment of already partitioned word arrays.
 void launch_pass_hist_dense(const Launch& L, const Words& in, const PassParams& pp,
                             uint32_t n_groups);
-void launch_pass_scatter_dense(const Launch& L, const Words& in, int n_words, const PassParams& pp,
-                               uint32_t n_groups, const Words& out);
+// pair_word >= 0: words pair_word / pair_word+1 (a two-word carry) live as 8-byte pairs in
+// in.w[pair_word] / out.w[pair_word] (what every pass writes for two-word carries); else -1
+void launch_pass_scatter_dense(const Launch& L, const Words& in, int n_words, int pair_word,
+                               const PassParams& pp, uint32_t n_groups, const Words& out);
 
 // Packed layout ({hashed key, carry} pairs in one array) for one key word + one carry word.
 void launch_pass_hist_packed(const Launch& L, const uint32_t* in_pairs, const PassParams& pp,
