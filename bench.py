@@ -7,7 +7,7 @@ N = 1  workload = BASELINE.json configs[1]: single JoinNode, synthetic 100M ⋈ 
        uniform keys, 1 INT32 payload column per side, plan
        Join(build_left=true, Scan(R){0,1}, Scan(S){0,1}, out={0,1,3}).
        One step = one rj_execute_resident() of that plan: Page-packed inputs already in
-       HBM, page decode + 2 radix passes per side + build/probe + Page-encoded result in
+       HBM, page decode + one histogram and 2 radix scatters per side + build/probe + Page-encoded result in
        HBM, including the result-size read-back.
 N > 1  one process per GPU (torch.distributed, backend nccl = RCCL): every rank holds a
        100M ⋈ 100M shard (weak scaling), stage A partitions by rank, ONE all-to-all over
@@ -23,6 +23,10 @@ import json
 import os
 import sys
 import time
+
+# multi-process GPU work on this platform needs dmabuf IPC (RCCL fails with
+# `hipIpcGetMemHandle: invalid argument` otherwise); the boxes export it, keep it if they do not
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "radix-join_amd"), os.path.join(ROOT, "tests")):
