@@ -1,6 +1,8 @@
 """All 113 JOB plans (tree shapes of the reference's plans.json) on the GPU vs the oracle,
 over synthetic IMDB-shaped inputs (the IMDB CSVs and DuckDB are not available offline, so the
 harness' DuckDB check is replaced by GPU == oracle on identical Plans)."""
+import os
+
 import pytest
 
 import _oracle
@@ -30,7 +32,12 @@ def test_job_plan(ctx, name):
     assert pl.sorted_rows(got) == pl.sorted_rows(want)
 
 
-@pytest.mark.parametrize("name", ["1a", "13d"])
+# RJ_JOB_AT_SCALE=all (soak runs) checks every plan at scale; the default keeps the two named in
+# BASELINE.json (the oracle needs ~140 s for all 113)
+_AT_SCALE = sorted(FX["queries"]) if os.environ.get("RJ_JOB_AT_SCALE") == "all" else ["1a", "13d"]
+
+
+@pytest.mark.parametrize("name", _AT_SCALE)
 def test_job_plans_at_scale(ctx, name):
     """BASELINE configs 1 and 5 at realistic input sizes: every scan's input is sized by
     PostgreSQL's Plan Rows estimate (pyrj.job.make_scaled_inputs; 3.9 M rows for 1a, 21.5 M for
@@ -42,5 +49,8 @@ def test_job_plans_at_scale(ctx, name):
     p = job.build_plan(FX["queries"][name], FX["schema"], tables, by_alias=True)
     got = capi.execute(p, ctx)
     want = _oracle.execute(p)
-    assert got.num_rows == want.num_rows > 0
-    assert pl.sorted_rows(got) == pl.sorted_rows(want)
+    assert got.num_rows == want.num_rows
+    if name in ("1a", "13d"):
+        assert want.num_rows > 0
+    if want.num_rows <= 200_000:
+        assert pl.sorted_rows(got) == pl.sorted_rows(want)
