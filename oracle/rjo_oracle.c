@@ -138,10 +138,9 @@ static int decode_column(const rj_column* col, uint64_t num_rows, rows* out, siz
                     ++data_idx;
                     ++row_idx;
                 } else {
-                    /* the reference does not bounds-check NULL rows (:339);
-                     * stay in bounds but keep the same accept/reject set for
-                     * well-formed inputs */
-                    if (row_idx >= num_rows) return fail(e, "row_idx");
+                    /* the reference does not bounds-check NULL rows (:339-340): a NULL
+                     * row past num_rows only advances row_idx (nothing is written), and
+                     * "row_idx" is raised only by a non-NULL value at or past the end */
                     ++row_idx;
                 }
             }
@@ -182,8 +181,9 @@ static int decode_column(const rj_column* col, uint64_t num_rows, rows* out, siz
                 const uint8_t* bitmap = page + RJ_PAGE_SIZE - (nr + 7) / 8;
                 uint32_t       data_idx = 0;
                 for (uint32_t i = 0; i < nr; ++i) {
-                    if (row_idx >= num_rows) return fail(e, "row_idx");
                     if (get_bit(bitmap, i)) {
+                        /* only a non-NULL value past the end raises (:418-420) */
+                        if (row_idx >= num_rows) return fail(e, "row_idx");
                         uint16_t    off = rd16(offs + (size_t)data_idx * 2);
                         cell*       c = &out->c[row_idx * out->w + ci];
                         const char* end = data_begin + off;

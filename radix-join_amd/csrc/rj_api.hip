@@ -60,6 +60,7 @@ int rj_context_create(rj_context** out, const rj_config* cfg) {
         c->prof.level = cfg && cfg->profile >= 2 ? 2 : 1;
         c->prof.stream = c->stream;
         c->radix_bits_override = cfg ? cfg->radix_bits : 0;
+        c->tune.from_env();
         *out = c.release();
     } catch (const rj::Error& e) {
         code = e.code;
@@ -156,16 +157,14 @@ int rj_execute(rj_context* ctx, const rj_plan* plan, rj_result** out) {
                 col_used[nd.base_table_id][nd.out_idx[k]] = true;
             }
         }
-        const char* dg = getenv("RJ_DIAG");
-        const bool  diag = dg && atoi(dg) >= 2;
+        const bool  diag = ctx->tune.diag >= 2;
         auto        t0 = std::chrono::steady_clock::now();
         const uint64_t m0 = ctx->pool.n_malloc, tr0 = ctx->pool.n_trim;
         const double   mm0 = ctx->pool.malloc_ms;
         auto        ms_since = [](std::chrono::steady_clock::time_point t) {
             return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
         };
-        const char* su = getenv("RJ_SYNC_UPLOAD");
-        if (su && atoi(su) > 0) {  // diagnostic: upload everything, then run the plan
+        if (ctx->tune.sync_upload > 0) {  // diagnostic: upload everything, then run the plan
             std::vector<std::unique_ptr<Table>> owned(plan->n_inputs);
             std::vector<Table*>                 ts(plan->n_inputs, nullptr);
             rj_input                            none{};

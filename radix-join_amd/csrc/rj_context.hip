@@ -1,9 +1,29 @@
 // rj_context.hip — context, HBM block cache, HIP-event profiler.
 #include <chrono>
+#include <cstdlib>
 
 #include "rj_internal.hpp"
 
 namespace rj {
+
+[[noreturn]] void launch_failed(const char* kernel, const char* what, bool unsupported) {
+    throw_fmt(unsupported ? RJ_ERR_UNSUPPORTED : RJ_ERR_DEVICE, "launch %s: %s", kernel, what);
+}
+
+static int env_int(const char* name, int def) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : def;
+}
+
+void Tuning::from_env() {
+    p1_bits = env_int("RJ_TUNE_P1_BITS", p1_bits);
+    fine = env_int("RJ_TUNE_FINE", fine);
+    pack = env_int("RJ_TUNE_PACK", pack);
+    tpg1 = env_int("RJ_TUNE_TPG1", tpg1);
+    bcast = env_int("RJ_TUNE_BCAST", bcast);
+    diag = env_int("RJ_DIAG", diag);
+    sync_upload = env_int("RJ_SYNC_UPLOAD", sync_upload);
+}
 
 // ---------------------------------------------------------------- DevPool --
 static size_t round_size(size_t n) {

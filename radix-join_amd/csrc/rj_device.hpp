@@ -73,7 +73,12 @@ constexpr int PT_TILE    = PT_THREADS * PT_ITEMS; // 16384 tuples = 64 KiB of LD
 constexpr int PT_MAXF    = 512;                   // max fan-out per pass (9 bits)
 constexpr int PT_MAXBITS = 9;
 constexpr int PT_FINEBITS = 15;                   // fine (two-digit) histogram: 2^15 bins = 128 KiB of LDS
+constexpr int LDS_BYTES  = 160 * 1024;            // per CU (and the most one workgroup may declare)
 static_assert(PT_THREADS >= PT_MAXF, "thread d scans digit d");
+// static LDS of the partition kernels: staging tile of 8-byte pairs + three digit arrays + wave sums
+static_assert(PT_TILE * 8 + 3 * PT_MAXF * 4 + (PT_THREADS / 64) * 4 <= LDS_BYTES,
+              "scatter tile does not fit the 160 KiB of LDS");
+static_assert((4 << PT_FINEBITS) <= LDS_BYTES, "fine histogram does not fit the LDS");
 static_assert(PT_TILE <= 65536, "ranks are packed into 16 bits");
 static_assert(PT_ITEMS % 4 == 0, "full tiles are loaded as 16-byte vectors");
 
@@ -117,6 +122,7 @@ constexpr int jn_min_waves(int table_words) {
     return w > 8 ? 8 : (w < 1 ? 1 : w);
 }
 static_assert(JN_RPT % 4 == 0 && JN_SPT % 4 == 0, "tuples are loaded as 16-byte vectors");
+static_assert(JN_CAP * 4 * 4 + JN_CAP + 1024 <= 160 * 1024, "a four-array join table does not fit the LDS");
 #ifndef RJ_JN_PPW
 #define RJ_JN_PPW 1
 #endif

@@ -57,11 +57,6 @@ struct JoinSpec {
     int                   forced_bits = 0;
 };
 
-int tune(const char* name, int def) {
-    const char* v = getenv(name);
-    return v && *v ? atoi(v) : def;
-}
-
 uint32_t ceil_log2(uint64_t v) {
     uint32_t b = 0;
     while ((uint64_t(1) << b) < v) ++b;
@@ -298,8 +293,8 @@ class Exec {
         std::vector<uint32_t> pbits(passes, bits / passes);
         for (uint32_t i = 0; i < bits % passes; ++i) pbits[i]++;
         // tuning knobs (experiments): RJ_TUNE_P1_BITS moves bits between pass 1 and pass 2
-        if (passes == 2 && tune("RJ_TUNE_P1_BITS", 0) > 0) {
-            uint32_t b1 = (uint32_t)tune("RJ_TUNE_P1_BITS", 0);
+        if (passes == 2 && ctx->tune.p1_bits > 0) {
+            uint32_t b1 = (uint32_t)ctx->tune.p1_bits;
             if (b1 < bits && b1 <= PT_MAXBITS && bits - b1 <= PT_MAXBITS) {
                 pbits[0] = b1;
                 pbits[1] = bits - b1;
@@ -310,11 +305,11 @@ class Exec {
         // single read of the source, the scatters reserve their ranges tile by tile, and the
         // second histogram pass (4 B/tuple) disappears.
         const bool fine = passes == 2 && bits <= (uint32_t)PT_FINEBITS && !external &&
-                          tune("RJ_TUNE_FINE", 1) != 0;
+                          ctx->tune.fine != 0;
         // key + one carry word travel as 8-byte pairs in one array (half the streams, twice the
         // bytes per run); RJ_TUNE_PACK: 0 = never, 1 = every plan, 2 = fine-histogram plans only
         // (a later pass' plain histogram reads 8 instead of 4 bytes per tuple from pairs)
-        const int pack_mode = tune("RJ_TUNE_PACK", 1);
+        const int pack_mode = ctx->tune.pack;
         P.packed = !external && KW == 1 && CW == 1 && (pack_mode == 1 || (pack_mode == 2 && fine));
         BufP  A[MAX_WORDS], B[MAX_WORDS];
         Words wa{}, wb{};
@@ -367,7 +362,7 @@ class Exec {
             BufP     grp_start;
             if (p == 0) {
                 pp.tiles_per_group = tiles_per_group(n, 4096);
-                if (tune("RJ_TUNE_TPG1", 0) > 0) pp.tiles_per_group = (uint32_t)tune("RJ_TUNE_TPG1", 0);
+                if (ctx->tune.tpg1 > 0) pp.tiles_per_group = (uint32_t)ctx->tune.tpg1;
                 uint64_t gt = (uint64_t)pp.tiles_per_group * PT_TILE;
                 n_groups = (uint32_t)((n + gt - 1) / gt);
             } else {
@@ -537,7 +532,7 @@ class Exec {
                 (bs.rel->n >> (2 * PT_MAXBITS)) <= (uint64_t)(JN_RMAX * 0.95))
                 bits = 2 * PT_MAXBITS;
             bits = std::min<uint32_t>(std::max<uint32_t>(bits, 1), 27);
-            if (tune("RJ_DIAG", 0) >= 2)
+            if (ctx->tune.diag >= 2)
                 fprintf(stderr, "[rj diag] join build=%llu probe=%llu bits=%u cw=%d/%d\n",
                         (unsigned long long)bs.rel->n, (unsigned long long)ps.rel->n, bits, bs.CW, ps.CW);
 
@@ -558,7 +553,7 @@ class Exec {
             // A build side that fits one LDS table is not partitioned at all: every workgroup builds
             // the same table and streams a slice of the probe child past it (k_join_bcast)
             const bool bcast = bs.rel->n <= (uint64_t)JN_RMAX && js.forced_bits <= 0 && !js.prehashed &&
-                               tune("RJ_TUNE_BCAST", 1) != 0;
+                               ctx->tune.bcast != 0;
             Parted   PB, PP;
             uint32_t max_tasks = 0;
             BufP     tasks;
@@ -641,7 +636,7 @@ class Exec {
                 jp.heavy_tasks = tasks->as<uint32_t>();
                 jp.n_heavy = counters->as<uint32_t>() + 2;
                 BufP diag;
-                if (tune("RJ_DIAG", 0)) {
+                if (ctx->tune.diag) {
                     diag = ctx->buf(16 * 8);
                     RJ_HIP(hipMemsetAsync(diag->p, 0, 16 * 8, ctx->stream));
                     jp.diag = diag->as<unsigned long long>();
@@ -795,7 +790,7 @@ class Exec {
             throw_fmt(RJ_ERR_ARG, "VARCHAR column without provenance");
         const Table*       t = table_by_id((uint64_t)src.vc_table);
         const TableColumn& tc = t->cols[src.vc_col];
-        const bool diag = tune("RJ_DIAG", 0) >= 2;
+        const bool diag = ctx->tune.diag >= 2;
         auto       tv0 = std::chrono::steady_clock::now();
         std::vector<uint32_t> ids(n);
         RJ_HIP(hipMemcpyAsync(ids.data(), dev_rowids, n * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -146,20 +146,54 @@ __device__ __forceinline__ void stream_store(const OutStream& o, uint64_t row, u
 }
 
 // ================================================================= K0 headers
-// Reads `u16 n_rows @0, u16 n_nonnull @2` of every page (layout: reference
-// src/build_table.cpp:326-329).  A column is "regular" when every page but the
-// last holds exactly rows_full non-NULL rows; regular columns are addressed in
-// place by every later kernel, the others go through K1 once.
-__global__ void k_page_headers(const uint8_t* pages, uint32_t n_pages, uint32_t rows_full,
-                               uint32_t* page_rows, unsigned long long* flags) {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per page: reads `u16 n_rows @0` and the validity bitmap in the last
+// (n_rows+7)/8 bytes (layout: reference src/build_table.cpp:326-331).  A column is
+// "regular" when every page but the last holds exactly rows_full rows and every bitmap bit
+// of every page is set; regular columns are addressed in place by every later kernel, the
+// others go through K1 once.  The reference decodes fixed-width pages from the bitmap alone
+// and never reads the header's non-null count (:332-343), so neither does this.
+__global__ __launch_bounds__(256) void k_page_headers(const uint8_t* pages, uint32_t n_pages,
+                                                      uint32_t rows_full, uint32_t* page_rows,
+                                                      unsigned long long* flags) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (p >= n_pages) return;
-    uint32_t hdr = *reinterpret_cast<const uint32_t*>(pages + (size_t)p * PAGE_BYTES);
-    uint32_t nr = hdr & 0xffffu, nv = hdr >> 16;
+    const uint8_t* page = pages + (size_t)p * PAGE_BYTES;
+    const uint32_t nr = *reinterpret_cast<const uint16_t*>(page);
+    const uint32_t nb = (nr + 7) / 8;
+    const uint8_t* bm = page + PAGE_BYTES - nb;
+    bool           ones = true;
+    for (uint32_t k = lane; k < nb; k += 64) {
+        const uint32_t rem = nr - k * 8u;
+        const uint32_t want = rem >= 8 ? 0xffu : ((1u << rem) - 1u);
+        ones = ones && ((bm[k] & want) == want);
+    }
+    const bool all_ones = __ballot(!ones) == 0;
+    if (lane != 0) return;
     page_rows[p] = nr;
-    bool irregular = (nv != nr) || (p + 1 < n_pages ? nr != rows_full : (nr > rows_full || nr == 0));
+    bool irregular = !all_ones || (p + 1 < n_pages ? nr != rows_full : (nr > rows_full || nr == 0));
     if (irregular) atomicAdd(&flags[0], 1ull);
     atomicAdd(&flags[1], (unsigned long long)nr);
+}
+
+// "row_idx" rule of Table::from_columnar (reference src/build_table.cpp:334-336): the
+// reference throws only when a NON-NULL value lands at a row index >= num_rows; NULL rows
+// past the end are tolerated.  One wave per page; flag[0] counts offending pages.
+__global__ __launch_bounds__(256) void k_rows_beyond(const uint8_t* pages, uint32_t n_pages,
+                                                     const uint32_t* row_base, uint64_t num_rows,
+                                                     unsigned long long* flag) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (p >= n_pages) return;
+    const uint8_t* page = pages + (size_t)p * PAGE_BYTES;
+    const uint32_t nr = *reinterpret_cast<const uint16_t*>(page);
+    const uint64_t rb = row_base[p];
+    if (rb + nr <= num_rows) return;
+    const uint8_t* bm = page + PAGE_BYTES - (nr + 7) / 8;
+    bool           bad = false;
+    for (uint32_t i = lane; i < nr; i += 64)
+        if (rb + i >= num_rows && ((bm[i >> 3] >> (i & 7u)) & 1u)) bad = true;
+    if (__ballot(bad) != 0 && lane == 0) atomicAdd(flag, 1ull);
 }
 
 // ================================================================== K1 decode
@@ -911,8 +945,9 @@ __global__ void k_heavy_tasks(const uint32_t* offR, const uint32_t* offS, uint32
         uint32_t k = b + t;
         if (k >= max_tasks) break;  // cannot happen: max_tasks >= 2*|S|/JN_HEAVY + 1
         tasks[3 * k + 0] = q;
-        tasks[3 * k + 1] = sb + t * JN_HEAVY;
-        tasks[3 * k + 2] = min(se, sb + (t + 1) * JN_HEAVY);
+        // bounds in 64 bits: a partition ending within JN_HEAVY of 2^32 must not wrap
+        tasks[3 * k + 1] = (uint32_t)((uint64_t)sb + (uint64_t)t * JN_HEAVY);
+        tasks[3 * k + 2] = (uint32_t)min((uint64_t)se, (uint64_t)sb + (uint64_t)(t + 1) * JN_HEAVY);
     }
 }
 
@@ -1699,6 +1734,8 @@ __global__ __launch_bounds__(256) void k_encode_nullable(const uint8_t* values, 
 }
 
 // ================================================================== launchers
+// A rejected launch (LDS or launch-bounds mismatch of a tuning variant, wrong device) must not
+// pass silently: the stream would "succeed" and the join return stale buffers with RJ_OK.
 #define RJ_KLAUNCH(L, NAME, KERNEL, GRID, BLOCK, ...)                                          \
     do {                                                                                       \
         hipEvent_t _ev0 = nullptr, _ev1 = nullptr;                                             \
@@ -1707,13 +1744,22 @@ __global__ __launch_bounds__(256) void k_encode_nullable(const uint8_t* values, 
                                   0, __VA_ARGS__);                                             \
         else                                                                                   \
             hipLaunchKernelGGL(KERNEL, dim3(GRID), dim3(BLOCK), 0, (L).stream, __VA_ARGS__);   \
+        hipError_t _le = hipGetLastError();                                                    \
+        if (_le != hipSuccess) launch_failed(NAME, hipGetErrorString(_le), false);             \
     } while (0)
 
 void launch_page_headers(const Launch& L, const uint8_t* pages, uint32_t n_pages, uint32_t rows_full,
                          uint32_t* page_rows, unsigned long long* flags) {
     if (!n_pages) return;
-    RJ_KLAUNCH(L, "page_headers", k_page_headers, (n_pages + 255) / 256, 256, pages, n_pages,
+    RJ_KLAUNCH(L, "page_headers", k_page_headers, (n_pages + 3) / 4, 256, pages, n_pages,
                rows_full, page_rows, flags);
+}
+
+void launch_rows_beyond(const Launch& L, const uint8_t* pages, uint32_t n_pages,
+                        const uint32_t* row_base, uint64_t num_rows, unsigned long long* flag) {
+    if (!n_pages) return;
+    RJ_KLAUNCH(L, "rows_beyond", k_rows_beyond, (n_pages + 3) / 4, 256, pages, n_pages, row_base,
+               num_rows, flag);
 }
 
 void launch_decode_pages(const Launch& L, const uint8_t* pages, uint32_t n_pages, int width,
@@ -1794,7 +1840,7 @@ void launch_pass_scatter_src(const Launch& L, const TupleSrc& src, int key_words
     case 20: scatter_src_t<2, 0>(L, src, pp, n_groups, out); break;
     case 21: scatter_src_t<2, 1>(L, src, pp, n_groups, out); break;
     case 22: scatter_src_t<2, 2>(L, src, pp, n_groups, out); break;
-    default: break;
+    default: launch_failed("pass1_scatter", "no kernel for this key/carry word count", true);
     }
 }
 
@@ -1829,7 +1875,7 @@ void launch_pass_scatter_dense(const Launch& L, const Words& in, int n_words, in
         RJ_KLAUNCH(L, "pass2_scatter", (k_pass_scatter<4, DenseLoaderT<2>, 2>), n_groups, PT_THREADS,
                    DenseLoaderT<2>{in}, pp, out);
         break;
-    default: break;
+    default: launch_failed("pass2_scatter", "no kernel for this word layout", true);
     }
 }
 
@@ -1927,7 +1973,7 @@ void launch_join(const Launch& L, int key_words, int cw_build, int cw_probe, con
     case 220: join_t<2, 2, 0>(L, jp, grid); break;
     case 221: join_t<2, 2, 1>(L, jp, grid); break;
     case 222: join_t<2, 2, 2>(L, jp, grid); break;
-    default: break;
+    default: launch_failed("join_build_probe", "no kernel for this key/carry word count", true);
     }
 }
 
@@ -1958,7 +2004,7 @@ void launch_join_bcast(const Launch& L, int key_words, int cw_build, int cw_prob
     case 220: join_bcast_t<2, 2, 0>(L, bp, grid); break;
     case 221: join_bcast_t<2, 2, 1>(L, bp, grid); break;
     case 222: join_bcast_t<2, 2, 2>(L, bp, grid); break;
-    default: break;
+    default: launch_failed("join_broadcast", "no kernel for this key/carry word count", true);
     }
 }
 

@@ -16,11 +16,19 @@ struct Launch {
     void* self;
 };
 
+// A launch the runtime rejected, or a template combination no kernel exists for: throws
+// rj::Error (RJ_ERR_DEVICE / RJ_ERR_UNSUPPORTED).  Implemented in rj_context.hip.
+[[noreturn]] void launch_failed(const char* kernel, const char* what, bool unsupported);
+
 // ---- page metadata / decode (replaces Table::from_columnar, reference
 //      src/build_table.cpp:312-436, for fixed-width columns)
 // flags[0] = #pages breaking the "regular" shape, flags[1..2] = total rows (u64)
 void launch_page_headers(const Launch& L, const uint8_t* pages, uint32_t n_pages, uint32_t rows_full,
                          uint32_t* page_rows, unsigned long long* flags);
+// flag[0] += pages that hold a NON-NULL value at a row index >= num_rows (the reference's
+// "row_idx" error, src/build_table.cpp:334-336); row_base = exclusive scan of the page rows
+void launch_rows_beyond(const Launch& L, const uint8_t* pages, uint32_t n_pages,
+                        const uint32_t* row_base, uint64_t num_rows, unsigned long long* flag);
 void launch_decode_pages(const Launch& L, const uint8_t* pages, uint32_t n_pages, int width,
                          const uint32_t* row_base, uint64_t num_rows, uint8_t* values,
                          uint8_t* valid);

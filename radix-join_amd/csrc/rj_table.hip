@@ -35,10 +35,22 @@ static void analyse_column(Context* ctx, TableColumn& c, uint64_t num_rows) {
     RJ_HIP(hipMemcpyAsync(h, flags->p, 16, hipMemcpyDeviceToHost, ctx->stream));
     ctx->sync();
     c.page_rows_total = h[1];
-    // more rows in the pages than the table declares: the reference throws
-    // std::runtime_error("row_idx") (src/build_table.cpp:334-336)
-    if (h[1] > num_rows) throw_fmt(RJ_ERR_DATA, "row_idx");
     c.regular = (h[0] == 0) && (h[1] == num_rows);
+    if (h[1] > 0xfffffff0ull) throw_fmt(RJ_ERR_UNSUPPORTED, "column pages hold more than 2^32 rows");
+    if (h[1] > num_rows) {
+        // The pages hold more rows than the table declares.  The reference throws
+        // std::runtime_error("row_idx") only when a NON-NULL value lands at a row index
+        // >= num_rows (src/build_table.cpp:334-336); NULL rows past the end are tolerated.
+        BufP row_base = ctx->buf((c.n_pages + 1) * 4);
+        launch_scan_bins(L, c.page_rows->as<uint32_t>(), (uint32_t)c.n_pages,
+                         row_base->as<uint32_t>(), nullptr);
+        RJ_HIP(hipMemsetAsync(flags->p, 0, 8, ctx->stream));
+        launch_rows_beyond(L, c.dev_pages, (uint32_t)c.n_pages, row_base->as<uint32_t>(), num_rows,
+                           flags->as<unsigned long long>());
+        RJ_HIP(hipMemcpyAsync(h, flags->p, 8, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->sync();
+        if (h[0] != 0) throw_fmt(RJ_ERR_DATA, "row_idx");
+    }
 }
 
 Table* table_adopt(Context* ctx, uint64_t num_rows, uint64_t n_cols, const int32_t* types,
@@ -69,6 +81,26 @@ Table* table_adopt(Context* ctx, uint64_t num_rows, uint64_t n_cols, const int32
 // ---- upload = prepare (caller's thread: shape the Table, reserve HBM) + fill (any thread:
 //      gather into pinned staging, H2D in 32 MiB chunks, page headers read on the way)
 namespace {
+
+// every validity bit of the page's nr rows set?  (bitmap = last (nr+7)/8 bytes)
+inline bool bitmap_all_ones(const uint8_t* page, uint32_t nr) {
+    const uint32_t nb = (nr + 7) / 8;
+    const uint8_t* bm = page + PAGE_BYTES - nb;
+    const uint32_t full = nr / 8;
+    uint32_t       k = 0;
+    for (; k + 8 <= full; k += 8) {
+        uint64_t w;
+        memcpy(&w, bm + k, 8);
+        if (w != ~0ull) return false;
+    }
+    for (; k < full; ++k)
+        if (bm[k] != 0xff) return false;
+    if (nr & 7u) {
+        const uint8_t want = (uint8_t)((1u << (nr & 7u)) - 1u);
+        if ((bm[full] & want) != want) return false;
+    }
+    return true;
+}
 
 struct UploadLane {
     hipStream_t stream = nullptr;
@@ -164,13 +196,17 @@ void table_fill(Table* t, const rj_input* in, UploadLane& lane) {
                 uint64_t irr = 0, tot = 0;
                 for (size_t p = b; p < e; ++p) {
                     copy_page(s + p * PAGE_BYTES, pages[p]);
-                    uint32_t hdr;
-                    memcpy(&hdr, pages[p], 4);
-                    uint32_t nr = hdr & 0xffffu, nv = hdr >> 16;
+                    const uint8_t* pg = static_cast<const uint8_t*>(pages[p]);
+                    uint16_t       nr16;
+                    memcpy(&nr16, pg, 2);
+                    const uint32_t nr = nr16;
                     uint64_t gp = p0 + p;
                     prow[gp] = nr;
                     tot += nr;
-                    irr += (nv != nr) ||
+                    // regular = full page + every validity bit set (the reference decodes from
+                    // the bitmap alone, src/build_table.cpp:326-343; the header's non-null
+                    // count is never read for fixed-width pages)
+                    irr += !bitmap_all_ones(pg, nr) ||
                            (gp + 1 < hc.n_pages ? nr != rows_full : (nr > rows_full || nr == 0));
                 }
                 copy_pages_fence();
@@ -185,8 +221,22 @@ void table_fill(Table* t, const rj_input* in, UploadLane& lane) {
         }
         c.page_rows_total = total.load();
         // more rows in the pages than the table declares: the reference throws
-        // std::runtime_error("row_idx") (src/build_table.cpp:334-336)
-        if (c.page_rows_total > t->num_rows) throw_fmt(RJ_ERR_DATA, "row_idx");
+        // std::runtime_error("row_idx") when a NON-NULL value lands at a row index >= num_rows
+        // (src/build_table.cpp:334-336); trailing NULL rows are tolerated.  Rare: serial walk.
+        if (c.page_rows_total > t->num_rows) {
+            uint64_t rb = 0;
+            for (uint64_t p = 0; p < hc.n_pages; ++p) {
+                const uint32_t nr = prow[p];
+                if (rb + nr > t->num_rows) {
+                    const uint8_t* pg = static_cast<const uint8_t*>(hc.pages[p]);
+                    const uint8_t* bm = pg + PAGE_BYTES - (nr + 7) / 8;
+                    for (uint32_t i = 0; i < nr; ++i)
+                        if (rb + i >= t->num_rows && ((bm[i >> 3] >> (i & 7u)) & 1u))
+                            throw_fmt(RJ_ERR_DATA, "row_idx");
+                }
+                rb += nr;
+            }
+        }
         c.regular = irregular.load() == 0 && c.page_rows_total == t->num_rows;
         if (!c.regular)  // K1 needs the rows per page on the device
             RJ_HIP(hipMemcpyAsync(c.page_rows->p, prow, hc.n_pages * 4, hipMemcpyHostToDevice,

@@ -127,28 +127,44 @@ def unpack_fixed(pages: np.ndarray, num_rows: int, dtype: int):
         return values, valid
     hv = pages[:, :4].copy().view(np.uint16)
     nr_all = hv[:, 0].astype(np.int64)
-    nv_all = hv[:, 1].astype(np.int64)
-    if nr_all.sum() > num_rows:
-        raise RuntimeError("row_idx")
     cap = rows_per_full_page(dtype)
-    if np.array_equal(nr_all, nv_all) and (nr_all[:-1] == cap).all() and nr_all[-1] <= cap:
-        # dense fast path: no NULLs, full pages
+    tot = int(nr_all.sum())
+    if tot <= num_rows and (nr_all[:-1] == cap).all() and 0 < nr_all[-1] <= cap and _all_valid(pages, nr_all):
+        # dense fast path: full pages, every validity bit set
         body = pages[:, hdr : hdr + cap * w].copy().view(npdt)
-        tot = int(nr_all.sum())
-        values[:tot] = body.reshape(-1)[: (pages.shape[0] - 1) * cap + int(nr_all[-1])]
+        values[:tot] = body.reshape(-1)[:tot]
         valid[:tot] = True
         return values, valid
+    # general path = the reference's loop (src/build_table.cpp:326-343): decoded from the bitmap
+    # alone (the header's non-null count is never read); "row_idx" only for a NON-NULL value at
+    # a row index >= num_rows, NULL rows past the end just advance the row counter
     row = 0
     for pi in range(pages.shape[0]):
-        nr, nv = int(nr_all[pi]), int(nv_all[pi])
+        nr = int(nr_all[pi])
         nb = (nr + 7) // 8
         bits = np.unpackbits(pages[pi, PAGE_SIZE - nb :], bitorder="little")[:nr].astype(bool)
-        vals = pages[pi, hdr : hdr + nv * w].copy().view(npdt)
         idx = np.nonzero(bits)[0]
+        if idx.shape[0] and row + int(idx[-1]) >= num_rows:
+            raise RuntimeError("row_idx")
+        vals = pages[pi, hdr : hdr + idx.shape[0] * w].copy().view(npdt)
         values[row + idx] = vals[: idx.shape[0]]
         valid[row + idx] = True
         row += nr
     return values, valid
+
+
+def _all_valid(pages: np.ndarray, nr_all: np.ndarray) -> bool:
+    """Every validity bit of every page's rows set?"""
+    for cnt in np.unique(nr_all):
+        cnt = int(cnt)
+        nb = (cnt + 7) // 8
+        want = np.full(nb, 0xFF, dtype=np.uint8)
+        if cnt % 8:
+            want[-1] = (1 << (cnt % 8)) - 1
+        sel = pages[nr_all == cnt, PAGE_SIZE - nb :]
+        if nb and not ((sel & want) == want).all():
+            return False
+    return True
 
 
 # ------------------------------------------------------------------ VARCHAR --

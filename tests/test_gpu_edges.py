@@ -148,3 +148,59 @@ def test_context_reuse_and_result_lifetime(ctx):
     for ts in tabs:
         for t in ts:
             t.release()
+
+
+def test_header_lying_about_non_null_count_is_decoded_from_the_bitmap(ctx):
+    """A full page whose header claims n_nonnull == n_rows but whose bitmap has cleared bits: the
+    reference never reads the header's non-null count for fixed-width pages
+    (src/build_table.cpp:326-343), so those rows are NULL and their keys never match."""
+    n = pg.rows_per_full_page(pl.INT32) * 2
+    keys = np.arange(n, dtype=np.int32)
+    pages = pg.pack_fixed(keys, None, pl.INT32)
+    nb = (pg.rows_per_full_page(pl.INT32) + 7) // 8
+    pages[0, pg.PAGE_SIZE - nb] = 0xF0  # rows 0..3 of page 0 become NULL, header still says 1984/1984
+    lt = pl.ColumnarTable(n, [pl.Column(pl.INT32, pages), pl.Column(pl.INT32, pg.pack_fixed(keys, None, pl.INT32))])
+    rt = pl.make_table([(pl.INT32, keys[:100].copy()), (pl.INT32, keys[:100].copy())])
+    both = [(0, pl.INT32), (1, pl.INT32)]
+    for resident in (False, True):
+        plan = join2(lt, rt, False, 0, 0, both, both, [(0, pl.INT32), (1, pl.INT32), (3, pl.INT32)])
+        want = _oracle.execute(plan)
+        if resident:
+            import torch
+
+            tabs = []
+            for t in plan.inputs:
+                dev = [torch.from_numpy(c.pages.copy()).cuda() for c in t.columns]
+                tabs.append(ctx.adopt_device(t.num_rows, [c.type for c in t.columns], [d.data_ptr() for d in dev], [d.shape[0] for d in dev], keep=dev))
+            res = ctx.execute_resident(plan, tabs)
+            got = res.to_table()
+            res.free()
+            for t in tabs:
+                t.release()
+        else:
+            got = capi.execute(plan, ctx)
+        # the values sitting in the first slots of page 0 shift: 96 rows match, not 100
+        assert got.num_rows == want.num_rows
+        assert pl.sorted_rows(got) == pl.sorted_rows(want)
+
+
+def test_trailing_null_rows_beyond_num_rows_are_tolerated(ctx):
+    """reference src/build_table.cpp:334-340: only a NON-NULL value at a row index >= num_rows
+    raises "row_idx"; NULL rows past the end just advance the counter"""
+    vals = np.arange(3000, dtype=np.int32)
+    valid = np.ones(3000, bool)
+    valid[2990:] = False
+    t = pl.make_table([(pl.INT32, vals, valid), (pl.INT32, vals)])
+    t.columns[1] = pl.Column(pl.INT32, pg.pack_fixed(vals[:2990], None, pl.INT32))
+    t.num_rows = 2990
+    other = pl.make_table([(pl.INT32, np.arange(0, 3000, 3, dtype=np.int32)), (pl.INT32, np.arange(1000, dtype=np.int32))])
+    both = [(0, pl.INT32), (1, pl.INT32)]
+    check(ctx, join2(t, other, True, 0, 0, both, both, [(0, pl.INT32), (1, pl.INT32), (3, pl.INT32)]), small=False)
+    # ... and a non-NULL value past the end still raises, on both paths
+    t.num_rows = 2980
+    t.columns[1] = pl.Column(pl.INT32, pg.pack_fixed(vals[:2980], None, pl.INT32))
+    plan = join2(t, other, True, 0, 0, both, both, [(0, pl.INT32), (1, pl.INT32), (3, pl.INT32)])
+    with pytest.raises(capi.RjError, match="row_idx"):
+        capi.execute(plan, ctx)
+    with pytest.raises(RuntimeError, match="row_idx"):
+        _oracle.execute(plan)

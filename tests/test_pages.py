@@ -72,3 +72,24 @@ def test_varchar_roundtrip_and_long_strings():
     assert pg.unpack_varchar(ours, n) == strings
     assert _oracle.decode_varchar(pl.Column(pg.VARCHAR, ours), n) == strings
     assert pg.unpack_varchar(ref, n) == strings
+
+
+def test_row_idx_rule_follows_the_reference_loop():
+    """reference src/build_table.cpp:332-343: "row_idx" only when a NON-NULL value lands at a
+    row index >= num_rows; NULL rows past the end are tolerated, and fixed-width pages are
+    decoded from the bitmap alone (the header's non-null count is never read)"""
+    vals = np.arange(10, dtype=np.int32)
+    valid = np.ones(10, bool)
+    valid[7:] = False  # rows 7..9 NULL
+    pages = pg.pack_fixed(vals, valid, pg.INT32)
+    for decode in (lambda p, n: pg.unpack_fixed(p, n, pg.INT32), lambda p, n: _oracle.decode_fixed(pl.Column(pg.INT32, p), n)):
+        v, m = decode(pages, 7)  # three trailing NULL rows beyond num_rows: fine
+        assert m.all() and np.array_equal(v, vals[:7])
+        with pytest.raises(RuntimeError, match="row_idx"):
+            decode(pages, 6)  # row 6 is non-NULL and lands past the end
+    # a header that lies about the non-null count changes nothing: the bitmap decides
+    lying = pages.copy()
+    lying[0, 2:4].view(np.uint16)[0] = 10
+    for decode in (lambda p, n: pg.unpack_fixed(p, n, pg.INT32), lambda p, n: _oracle.decode_fixed(pl.Column(pg.INT32, p), n)):
+        v, m = decode(lying, 10)
+        assert np.array_equal(m, valid) and np.array_equal(v[valid], vals[valid])
