@@ -1,0 +1,86 @@
+"""The benchmarked configurations at FULL size, device-resident, checked in closed form
+(pyrj/workloads.py::verify_pk_fk: every probe row exactly once, with its own key and payload,
+next to the build row that holds that key) — plus one HIP-vs-oracle digest at 50 M x 50 M rows
+for the path that carries two-word (INT64) payloads next to a one-word key, whose partitions are
+12-byte tuples."""
+import numpy as np
+import pytest
+
+import _oracle
+from pyrj import capi
+from pyrj import plan as pl
+from pyrj import workloads as wl
+
+pytestmark = pytest.mark.gpu
+
+
+def run_and_verify(name):
+    import torch
+
+    ctx = capi.build_context()
+    try:
+        hbm = ctx.device_info()["hbm_bytes"]
+        rows = wl.WORKLOADS[name]["rows"]
+        if hbm < rows * 160:  # inputs + two ping-pong partition buffers per side + result
+            pytest.skip(f"{name} needs more HBM than this device has")
+        rel = wl.make_relations(name, torch.device("cuda"))
+        R = wl.adopt(ctx, [rel.rk, rel.rp])
+        S = wl.adopt(ctx, [rel.sk, rel.sp])
+        res = ctx.execute_resident(wl.join_plan(rel.payload_type), [R, S])
+        digest = wl.verify_pk_fk(res, rel)
+        assert digest["rows"] == rows
+        res.free()
+        R.release()
+        S.release()
+    finally:
+        capi.destroy_context(ctx)
+        torch.cuda.empty_cache()
+
+
+def test_config2_100m_uniform_full_size():
+    """BASELINE config 2: 100 M ⋈ 100 M INT32 uniform keys, INT32 payloads (fine histogram,
+    packed {key, carry} pairs, two 2^7/2^8-way passes)"""
+    run_and_verify("config2")
+
+
+def test_config3_1b_zipf_int64_full_size():
+    """BASELINE config 3: 1 B ⋈ 1 B, Zipf-0.9 probe keys (the hottest key owns ~1.3 % of the
+    probe side: heavy-task path), INT64 payloads (two-word carries), two 2^9-way passes"""
+    run_and_verify("config3")
+
+
+def test_uniform_1b_full_size():
+    """1 B ⋈ 1 B INT32 uniform keys, INT32 payloads (2^18 partitions: plain histograms on packed
+    pairs)"""
+    run_and_verify("uniform1b")
+
+
+def test_two_word_carry_path_50m_vs_oracle():
+    """KW = 1 / CW = 2 (INT32 key + INT64 payload on both sides) at 50 M x 50 M with a Zipf-0.9
+    probe side: HIP through the C-ABI (host pages in and out) against the oracle, by the
+    order-independent digest of the result rows"""
+    rng = np.random.default_rng(77)
+    n = 50_000_000
+    bk = rng.permutation(n).astype(np.int32)
+    w = 1.0 / np.arange(1, n + 1, dtype=np.float64) ** 0.9
+    cdf = np.cumsum(w)
+    cdf /= cdf[-1]
+    ranks = np.searchsorted(cdf, rng.random(n), side="right").clip(max=n - 1).astype(np.int64)
+    del w, cdf
+    pk = ((ranks * 7919 + 13) % n).astype(np.int32)
+    del ranks
+    bt = pl.make_table([(pl.INT32, bk), (pl.INT64, rng.integers(-(2**62), 2**62, n).astype(np.int64))])
+    pt = pl.make_table([(pl.INT32, pk), (pl.INT64, rng.integers(-(2**62), 2**62, n).astype(np.int64))])
+    p = wl.join_plan(pl.INT64)
+    p.new_input(bt)
+    p.new_input(pt)
+    ctx = capi.build_context()
+    try:
+        got = capi.execute(p, ctx)
+    finally:
+        capi.destroy_context(ctx)
+    dg = pl.table_digest(got)
+    del got
+    want = _oracle.execute(p)
+    assert want.num_rows == n
+    assert dg == pl.table_digest(want)
