@@ -126,7 +126,14 @@ static_assert(JN_CAP * 4 * 4 + JN_CAP + 1024 <= 160 * 1024, "a four-array join t
 #ifndef RJ_JN_PPW
 #define RJ_JN_PPW 1
 #endif
-constexpr int      JN_PPW     = RJ_JN_PPW;             // partitions per workgroup (software pipeline)
+#ifndef RJ_JN_PPW3
+#define RJ_JN_PPW3 4
+#endif
+// Partitions per workgroup: the next partition's loads are issued behind the current one's
+// probe (software pipeline).  Tables of two word arrays run two workgroups per CU, whose phases
+// overlap by themselves (pipelining them only spilled); tables of 3+ arrays run ONE 1024-thread
+// workgroup per CU, which would otherwise serialise load latency, build, probe and emit.
+constexpr int jn_ppw(int table_words) { return table_words >= 3 ? RJ_JN_PPW3 : RJ_JN_PPW; }
 constexpr uint32_t JN_HEAVY   = 32768;                 // probe tuples per task before splitting
 constexpr uint32_t JN_TARGET_BUILD = JN_RMAX * 3 / 4;  // mean build tuples per final partition
 

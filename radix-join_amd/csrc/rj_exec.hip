@@ -643,7 +643,8 @@ class Exec {
                 }
                 // one launch: heavy-task workgroups first, then one workgroup per partition
                 jp.heavy_grid = max_tasks;
-                launch_join(L, KW, bs.CW, ps.CW, jp, max_tasks + (PB.NP + JN_PPW - 1) / JN_PPW);
+                const uint32_t ppw = (uint32_t)jn_ppw(KW + bs.CW);
+                launch_join(L, KW, bs.CW, ps.CW, jp, max_tasks + (PB.NP + ppw - 1) / ppw);
                 if (diag) {
                     unsigned long long hd[16];
                     RJ_HIP(hipMemcpyAsync(hd, diag->p, sizeof hd, hipMemcpyDeviceToHost, ctx->stream));

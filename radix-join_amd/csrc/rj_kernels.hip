@@ -1014,7 +1014,8 @@ __global__ __launch_bounds__(jn_threads(KW + CWR), jn_min_waves(KW + CWR)) void 
     constexpr uint32_t SMASK = JN_CAP - 1;
     constexpr uint32_t BMASK = JN_CAP / 4 - 1;
 
-    // A workgroup joins JN_PPW consecutive partitions (main pass) or one heavy task.
+    // A workgroup joins PPW consecutive partitions (main pass) or one heavy task.
+    constexpr int PPW = jn_ppw(KW + CWR);
     struct Task {
         uint32_t q, rbeg, rend, sbeg, send;
         bool     active;
@@ -1036,8 +1037,8 @@ __global__ __launch_bounds__(jn_threads(KW + CWR), jn_min_waves(KW + CWR)) void 
             }
             return t;
         }
-        t.q = wg * JN_PPW + k;
-        if (k < JN_PPW && t.q < jp.NP) {
+        t.q = wg * PPW + k;
+        if (k < (uint32_t)PPW && t.q < jp.NP) {
             t.rbeg = jp.offR[t.q];
             t.rend = jp.offR[t.q + 1];
             t.sbeg = jp.offS[t.q];
@@ -1212,7 +1213,7 @@ __global__ __launch_bounds__(jn_threads(KW + CWR), jn_min_waves(KW + CWR)) void 
     };
 
     unsigned long long diag_t = jp.diag ? __builtin_amdgcn_s_memtime() : 0ull;
-    const uint32_t     n_tasks = heavy_wg ? 1u : (uint32_t)JN_PPW;
+    const uint32_t     n_tasks = heavy_wg ? 1u : (uint32_t)PPW;
     Task               cur = get_task(0);
     // haveR / haveS: the first build chunk / first probe sub-chunk of `cur` already sit in
     // rw / sw (prefetched while the previous partition was being probed / before its build)

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 CSV output (kernel stats + PMC passes) to the rj:: kernels.
 
-usage: prof_summary.py <gpurun_out/prof dir> <out.md>
+usage: prof_summary.py <gpurun_out/prof dir> <out.md> [<traffic.json> <workload> "<command profiled>"]
+  with the last three arguments the HBM bytes per launch of the hot kernels (2 x FETCH_SIZE +
+  WRITE_SIZE, gfx950 correction of MI355X_MICROARCH.md §HBM) are merged into <traffic.json>
+  under key <workload> — the file bench.py replays as `roofline.traffic`
   expects  <dir>/trace/**/_kernel_stats.csv   (--kernel-trace --stats)   or **/*_results.db (rocpd)
            <dir>/fetch/**/_counter_collection.csv (--pmc FETCH_SIZE)   [optional]
            <dir>/write/**/_counter_collection.csv (--pmc WRITE_SIZE)   [optional]
@@ -19,6 +22,21 @@ def short(name):
     if not m:
         return None
     return m.group(1) + (m.group(2) or "")
+
+
+def bench_name(sym):
+    """rocprof kernel symbol -> the name bench.py / the library's profiler uses"""
+    if sym.startswith("k_join<"):
+        return "join_build_probe"
+    if sym.startswith("k_fine_hist") or (sym.startswith("k_pass_hist") and "SrcLoader" in sym):
+        return "pass1_hist"
+    if sym.startswith("k_pass_hist"):
+        return "pass2_hist"
+    if sym.startswith("k_pass_scatter") and "SrcLoader" in sym:
+        return "pass1_scatter"
+    if sym.startswith("k_pass_scatter"):
+        return "pass2_scatter"
+    return None
 
 
 def _dbs(d, sub):
@@ -84,6 +102,29 @@ def main():
             lines.append(f"| `{s}` | {len(fetch.get(s, write.get(s, [])))} | {fv:.1f} | {2*fv:.1f} | {wv:.1f} |")
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
+    if len(sys.argv) >= 6:
+        import json
+
+        tpath, workload, cmd = sys.argv[3], sys.argv[4], sys.argv[5]
+        per = {}
+        for s in sorted(set(fetch) | set(write)):
+            name = bench_name(s)
+            if not name:
+                continue
+            fv, wv = max(fetch.get(s, [0])), max(write.get(s, [0]))
+            per[name] = {"bytes": (2 * fv + wv) * 1024.0, "read_bytes": 2 * fv * 1024.0, "write_bytes": wv * 1024.0, "kernel": s}
+        try:
+            allw = json.load(open(tpath))
+        except Exception:
+            allw = {}
+        allw[workload] = {
+            "source": f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of `{cmd}`; "
+                      "HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes: gfx950 reports half of a wide coalesced read, MI355X_MICROARCH.md §HBM)",
+            "bytes_per_launch": {k: v["bytes"] for k, v in per.items()},
+            "detail": per,
+        }
+        json.dump(allw, open(tpath, "w"), indent=1)
+        print("traffic ->", tpath, workload)
 
 
 if __name__ == "__main__":
