@@ -643,7 +643,7 @@ class Exec {
                 }
                 // one launch: heavy-task workgroups first, then one workgroup per partition
                 jp.heavy_grid = max_tasks;
-                const uint32_t ppw = (uint32_t)jn_ppw(KW + bs.CW);
+                const uint32_t ppw = join_partitions_per_workgroup(KW, bs.CW, jp);
                 launch_join(L, KW, bs.CW, ps.CW, jp, max_tasks + (PB.NP + ppw - 1) / ppw);
                 if (diag) {
                     unsigned long long hd[16];

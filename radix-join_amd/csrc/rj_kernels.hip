@@ -972,7 +972,8 @@ __global__ void k_heavy_tasks(const uint32_t* offR, const uint32_t* offS, uint32
 //   OM_PAGED32  key/bc/pc are all INT32 Page images (root of a plan, BASELINE config)
 //   OM_DENSE32  all present streams are dense 32-bit arrays (inner joins, row-index carries)
 //   OM_GENERIC  anything else (64-bit streams, mixed layouts, no key stream)
-enum { OM_GENERIC = 0, OM_PAGED32 = 1, OM_DENSE32 = 2 };
+//   OM_P32_64_64 INT32 key pages + INT64/FP64 pages for both carries (root of BASELINE config 3)
+enum { OM_GENERIC = 0, OM_PAGED32 = 1, OM_DENSE32 = 2, OM_P32_64_64 = 3 };
 
 // Diagnostic phase stamps (RJ_DIAG=1): thread 0 of every workgroup adds the cycles between
 // consecutive stamps to jp.diag[phase].  Shares only — the stamps perturb the timing.
@@ -986,14 +987,21 @@ enum { OM_GENERIC = 0, OM_PAGED32 = 1, OM_DENSE32 = 2 };
     } while (0)
 
 // PK: bit 0 = the build side, bit 1 = the probe side is a packed {hashed key, carry} array
-template <int KW, int CWR, int CWS, int OM, int PK>
-__global__ __launch_bounds__(jn_threads(KW + CWR), jn_min_waves(KW + CWR)) void k_join(JoinParams jp) {
+// TG: "tagged" table for one key word + a two-word build carry when the plan has >= 17 radix
+//     bits.  All hashed keys of a partition share their low radix bits, so the remaining
+//     (<= 15) high bits identify a key inside its partition: a slot is ONE word
+//     {tag16 | build tuple index << 16} and the carries sit densely, indexed by build tuple.
+//     Table = 32 KiB of slots + 32 KiB of carries (instead of three 32 KiB word arrays), so
+//     two 512-thread workgroups share a CU and overlap their phases like the two-word join.
+template <int KW, int CWR, int CWS, int OM, int PK, int TG>
+__global__ __launch_bounds__(jn_threads(TG ? 2 : KW + CWR), jn_min_waves(TG ? 2 : KW + CWR)) void k_join(JoinParams jp) {
     // Tables of three or four word arrays (64-bit keys, two-word build carries) leave room for
     // ONE workgroup per CU; it then runs 1024 threads, so the CU holds the same 16 waves as with
     // two 512-thread workgroups.  (Fetching wide build carries from the partitioned arrays on
     // emit instead — a two-array table — cost 7 of 17 ms at 1 B rows: 2 random 4-byte reads per
     // match are bound by the request rate of the vector memory path.)
-    constexpr int      TH = jn_threads(KW + CWR);
+    static_assert(!TG || (KW == 1 && CWR == 2), "tagged table: one key word + two-word build carry");
+    constexpr int      TH = jn_threads(TG ? 2 : KW + CWR);
     constexpr int      RPT = (JN_RMAX + TH - 1) / TH;  // build tuples per thread
     constexpr int      SPT = JN_SUB / TH;          // probe tuples per thread per sub-chunk
     constexpr int      SUB = JN_SUB;
@@ -1005,7 +1013,8 @@ __global__ __launch_bounds__(jn_threads(KW + CWR), jn_min_waves(KW + CWR)) void 
     // takes its slot from ONE LDS counter atomic — so nearly every lane finishes in a single
     // iteration and the wave does not pay the longest linear-probing chain of its 64 lanes.
     // A full bucket (4th slot used) sends probe and insert on to the next bucket.
-    __shared__ __attribute__((aligned(16))) uint32_t t_w[RW][JN_CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t t_w[TG ? 1 : RW][JN_CAP];
+    __shared__ __attribute__((aligned(16))) uint2    t_c2[TG ? JN_RMAX : 1];  // TG: carries by build tuple
     __shared__ __attribute__((aligned(16))) uint32_t t_cnt[JN_CAP / 4];
     __shared__ uint32_t s_wtot[TH / 64];
     __shared__ unsigned long long s_obase;
@@ -1015,7 +1024,7 @@ __global__ __launch_bounds__(jn_threads(KW + CWR), jn_min_waves(KW + CWR)) void 
     constexpr uint32_t BMASK = JN_CAP / 4 - 1;
 
     // A workgroup joins PPW consecutive partitions (main pass) or one heavy task.
-    constexpr int PPW = jn_ppw(KW + CWR);
+    constexpr int PPW = jn_ppw(TG ? 2 : KW + CWR);
     struct Task {
         uint32_t q, rbeg, rend, sbeg, send;
         bool     active;
@@ -1201,6 +1210,13 @@ __global__ __launch_bounds__(jn_threads(KW + CWR), jn_min_waves(KW + CWR)) void 
             *reinterpret_cast<uint32_t*>(jp.key.base + off) = klo;
             if constexpr (CWR >= 1) *reinterpret_cast<uint32_t*>(jp.bc.base + off) = b0;
             if constexpr (CWS >= 1) *reinterpret_cast<uint32_t*>(jp.pc.base + off) = p0;
+        } else if constexpr (OM == OM_P32_64_64) {
+            // one page/slot computation serves both 64-bit streams
+            const uint32_t r = (uint32_t)row, p4 = r / ROWS32, p8 = r / ROWS64;
+            *reinterpret_cast<uint32_t*>(jp.key.base + (size_t)p4 * PAGE_BYTES + HDR32 + (r - p4 * ROWS32) * 4u) = klo;
+            const size_t off8 = (size_t)p8 * PAGE_BYTES + HDR64 + (r - p8 * ROWS64) * 8u;
+            *reinterpret_cast<uint2*>(jp.bc.base + off8) = make_uint2(b0, b1);
+            *reinterpret_cast<uint2*>(jp.pc.base + off8) = make_uint2(p0, p1);
         } else if constexpr (OM == OM_DENSE32) {
             reinterpret_cast<uint32_t*>(jp.key.base)[row] = klo;
             if constexpr (CWR >= 1) reinterpret_cast<uint32_t*>(jp.bc.base)[row] = b0;
@@ -1226,8 +1242,14 @@ __global__ __launch_bounds__(jn_threads(KW + CWR), jn_min_waves(KW + CWR)) void 
             continue;
         }
         if (!haveR) load_build(cur.rbeg, min((uint32_t)JN_RMAX, cur.rend - cur.rbeg));
-        if (!haveS) load_probe(cur.sbeg, min((uint32_t)SUB, cur.send - cur.sbeg));
-        uint32_t sw_pos = cur.sbeg;  // which probe sub-chunk sw holds
+        // TGLATE (experiment): the tagged variant loads its first probe sub-chunk only after the
+        // build, when the build tuples' registers are free (peak live registers: 24 + 24 words)
+#ifndef RJ_TG_LATE
+#define RJ_TG_LATE 0
+#endif
+        constexpr bool late_probe = TG && RJ_TG_LATE;
+        if (!haveS && !late_probe) load_probe(cur.sbeg, min((uint32_t)SUB, cur.send - cur.sbeg));
+        uint32_t sw_pos = late_probe ? 0xffffffffu : cur.sbeg;  // which probe sub-chunk sw holds
         RJ_STAMP(0);  // loads issued
 
         // The low radix bits every hashed key of partition q shares, rebuilt from q
@@ -1243,7 +1265,8 @@ __global__ __launch_bounds__(jn_threads(KW + CWR), jn_min_waves(KW + CWR)) void 
                 rem >>= b;
             }
         }
-        const uint32_t EMPTY = qbits ^ 1u;
+        // TG: no tag has its bit 15 set (tags are < 2^15) and no build index reaches 0xffff
+        const uint32_t EMPTY = TG ? 0xffffffffu : (qbits ^ 1u);
 
         for (uint32_t rc = cur.rbeg; rc < cur.rend; rc += JN_RMAX) {
             const uint32_t rn = min((uint32_t)JN_RMAX, cur.rend - rc);
@@ -1264,12 +1287,17 @@ __global__ __launch_bounds__(jn_threads(KW + CWR), jn_min_waves(KW + CWR)) void 
                 uint32_t i = item_index(j, packR);
                 if (i < rn) {
                     uint32_t b = (rw[j][0] >> jp.radix_bits) & BMASK;
+                    if constexpr (TG) t_c2[i] = make_uint2(rw[j][1], rw[j][2]);
                     while (true) {
                         uint32_t pos = atomicAdd(&t_cnt[b], 1u);
                         if (pos < 4) {
                             const uint32_t slot = b * 4 + pos;
+                            if constexpr (TG) {
+                                t_w[0][slot] = (rw[j][0] >> jp.radix_bits) | (i << 16);
+                            } else {
 #pragma unroll
-                            for (int a = 0; a < RW; ++a) t_w[a][slot] = rw[j][a];
+                                for (int a = 0; a < RW; ++a) t_w[a][slot] = rw[j][a];
+                            }
                             break;
                         }
                         b = (b + 1) & BMASK;  // bucket full: overflow to the next one
@@ -1301,6 +1329,19 @@ __global__ __launch_bounds__(jn_threads(KW + CWR), jn_min_waves(KW + CWR)) void 
                         uint32_t b = (sw[j][0] >> jp.radix_bits) & BMASK;
                         while (true) {
                             const uint4 kv = *reinterpret_cast<const uint4*>(&t_w[0][b * 4]);
+                            if constexpr (TG) {
+                                const uint32_t tag = sw[j][0] >> jp.radix_bits;
+                                const uint32_t eq = (uint32_t)((kv.x & 0xffffu) == tag) | ((uint32_t)((kv.y & 0xffffu) == tag) << 1) |
+                                                    ((uint32_t)((kv.z & 0xffffu) == tag) << 2) | ((uint32_t)((kv.w & 0xffffu) == tag) << 3);
+                                if (eq) {
+                                    // f = build tuple index of the FIRST match (its carries: t_c2[f])
+                                    if (m[j] == 0) f[j] = ((eq & 1u) ? kv.x : (eq & 2u) ? kv.y : (eq & 4u) ? kv.z : kv.w) >> 16;
+                                    m[j] += (uint32_t)__popc(eq);
+                                }
+                                if (kv.w == EMPTY) break;
+                                b = (b + 1) & BMASK;
+                                continue;
+                            }
                             uint32_t    eq = (uint32_t)(kv.x == sw[j][0]) | ((uint32_t)(kv.y == sw[j][0]) << 1) |
                                           ((uint32_t)(kv.z == sw[j][0]) << 2) | ((uint32_t)(kv.w == sw[j][0]) << 3);
                             if (KW == 2 && eq) {
@@ -1366,13 +1407,16 @@ __global__ __launch_bounds__(jn_threads(KW + CWR), jn_min_waves(KW + CWR)) void 
                 if (fits) {
                     // the build carry of a tuple's FIRST match sits at the remembered slot
                     // f[j]: issue those reads for all tuples before the first store
-                    uint32_t c0[SPT], c1[SPT];
+                    // (TG reads them row by row instead: its registers are spoken for)
+                    uint32_t c0[TG ? 1 : SPT], c1[TG ? 1 : SPT];
+                    if constexpr (!TG) {
 #pragma unroll
-                    for (int j = 0; j < SPT; ++j) {
-                        c0[j] = 0;
-                        c1[j] = 0;
-                        if constexpr (CWR >= 1) c0[j] = m[j] ? t_w[KW][f[j]] : 0u;
-                        if constexpr (CWR == 2) c1[j] = m[j] ? t_w[KW + 1][f[j]] : 0u;
+                        for (int j = 0; j < SPT; ++j) {
+                            c0[j] = 0;
+                            c1[j] = 0;
+                            if constexpr (CWR >= 1) c0[j] = m[j] ? t_w[KW][f[j]] : 0u;
+                            if constexpr (CWR == 2) c1[j] = m[j] ? t_w[KW + 1][f[j]] : 0u;
+                        }
                     }
 #pragma unroll
                     for (int j = 0; j < SPT; ++j) {
@@ -1389,7 +1433,37 @@ __global__ __launch_bounds__(jn_threads(KW + CWR), jn_min_waves(KW + CWR)) void 
                         }
                         const uint32_t p0 = CWS >= 1 ? sw[j][KW < SW ? KW : 0] : 0u;
                         const uint32_t p1 = CWS == 2 ? sw[j][SW - 1] : 0u;
-                        emit_row(row, klo, khi, c0[j], c1[j], p0, p1);
+                        if constexpr (TG) {
+                            const uint2 c = t_c2[f[j]];
+                            emit_row(row, klo, khi, c.x, c.y, p0, p1);
+                        } else {
+                            emit_row(row, klo, khi, c0[j], c1[j], p0, p1);
+                        }
+                        if constexpr (TG) {
+                            // duplicates of the build key (rare): walk the buckets again from the
+                            // home bucket and emit every match but the first
+                            if (m[j] > 1) {
+                                const uint32_t tag = sw[j][0] >> jp.radix_bits;
+                                uint32_t       left = m[j], b = tag & BMASK;
+                                while (left) {
+                                    const uint4 kv = *reinterpret_cast<const uint4*>(&t_w[0][b * 4]);
+                                    const uint32_t sv[4] = {kv.x, kv.y, kv.z, kv.w};
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        if ((sv[e] & 0xffffu) == tag && left) {
+                                            if (left != m[j]) {  // the first match went out above
+                                                ++row;
+                                                const uint2 c = t_c2[sv[e] >> 16];
+                                                emit_row(row, klo, khi, c.x, c.y, p0, p1);
+                                            }
+                                            --left;
+                                        }
+                                    }
+                                    b = (b + 1) & BMASK;
+                                }
+                            }
+                            continue;
+                        }
                         // duplicates of the build key occupy further slots of the same run
                         uint32_t left = m[j] - 1;
                         uint32_t slot = (f[j] + 1) & SMASK;
@@ -1909,9 +1983,37 @@ void launch_heavy_tasks(const Launch& L, const uint32_t* offR, const uint32_t* o
                n_heavy, max_tasks);
 }
 
+// tagged table (see k_join): one key word + two-word build carry, >= 17 radix bits
+#ifndef RJ_TG_ENABLE
+#define RJ_TG_ENABLE 1
+#endif
+static bool join_tagged(int key_words, int cw_build, const JoinParams& jp) {
+    return RJ_TG_ENABLE && key_words == 1 && cw_build == 2 && jp.radix_bits >= 17 && jp.radix_bits <= 31;
+}
+
 template <int KW, int CWR, int CWS, int PK>
 static void join_pk(const Launch& L, const JoinParams& jp, uint32_t grid) {
     const char* name = "join_build_probe";
+    if constexpr (KW == 1 && CWR == 2 && PK == 0) {
+        const bool p366 = CWS == 2 && jp.key.mode == ST_PAGED32 && jp.bc.mode == ST_PAGED64 &&
+                          jp.pc.mode == ST_PAGED64;
+        if (join_tagged(KW, CWR, jp)) {
+            if constexpr (CWS == 2) {
+                if (p366) {
+                    RJ_KLAUNCH(L, name, (k_join<KW, CWR, CWS, OM_P32_64_64, PK, 1>), grid, jn_threads(2), jp);
+                    return;
+                }
+            }
+            RJ_KLAUNCH(L, name, (k_join<KW, CWR, CWS, OM_GENERIC, PK, 1>), grid, jn_threads(2), jp);
+            return;
+        }
+        if constexpr (CWS == 2) {
+            if (p366) {
+                RJ_KLAUNCH(L, name, (k_join<KW, CWR, CWS, OM_P32_64_64, PK, 0>), grid, jn_threads(KW + CWR), jp);
+                return;
+            }
+        }
+    }
     // pick the straight-line emit variant when the stream layout allows it
     int om = OM_GENERIC;
     if (KW == 1 && CWR <= 1 && CWS <= 1) {
@@ -1924,15 +2026,15 @@ static void join_pk(const Launch& L, const JoinParams& jp, uint32_t grid) {
     }
     if constexpr (KW == 1 && CWR <= 1 && CWS <= 1) {
         if (om == OM_PAGED32) {
-            RJ_KLAUNCH(L, name, (k_join<KW, CWR, CWS, OM_PAGED32, PK>), grid, jn_threads(KW + CWR), jp);
+            RJ_KLAUNCH(L, name, (k_join<KW, CWR, CWS, OM_PAGED32, PK, 0>), grid, jn_threads(KW + CWR), jp);
             return;
         }
         if (om == OM_DENSE32) {
-            RJ_KLAUNCH(L, name, (k_join<KW, CWR, CWS, OM_DENSE32, PK>), grid, jn_threads(KW + CWR), jp);
+            RJ_KLAUNCH(L, name, (k_join<KW, CWR, CWS, OM_DENSE32, PK, 0>), grid, jn_threads(KW + CWR), jp);
             return;
         }
     }
-    RJ_KLAUNCH(L, name, (k_join<KW, CWR, CWS, OM_GENERIC, PK>), grid, jn_threads(KW + CWR), jp);
+    RJ_KLAUNCH(L, name, (k_join<KW, CWR, CWS, OM_GENERIC, PK, 0>), grid, jn_threads(KW + CWR), jp);
 }
 
 // the packed variants exist only for the shapes that can be packed
@@ -1950,6 +2052,10 @@ static void join_t(const Launch& L, const JoinParams& jp, uint32_t grid) {
         if (pk == 2) return join_pk<KW, CWR, CWS, 2>(L, jp, grid);
     }
     join_pk<KW, CWR, CWS, 0>(L, jp, grid);
+}
+
+uint32_t join_partitions_per_workgroup(int key_words, int cw_build, const JoinParams& jp) {
+    return (uint32_t)jn_ppw(join_tagged(key_words, cw_build, jp) ? 2 : key_words + cw_build);
 }
 
 void launch_join(const Launch& L, int key_words, int cw_build, int cw_probe, const JoinParams& jp,

@@ -77,6 +77,8 @@ void launch_pass_scatter_packed(const Launch& L, const uint32_t* in_pairs, const
 // ---- build + probe (replaces reference src/execute.cpp:196-249)
 void launch_heavy_tasks(const Launch& L, const uint32_t* offR, const uint32_t* offS, uint32_t NP,
                         uint32_t* tasks, uint32_t* n_heavy, uint32_t max_tasks);
+// grid = jp.heavy_grid + ceil(jp.NP / join_partitions_per_workgroup(...))
+uint32_t join_partitions_per_workgroup(int key_words, int cw_build, const JoinParams& jp);
 void launch_join(const Launch& L, int key_words, int cw_build, int cw_probe, const JoinParams& jp,
                  uint32_t grid);
 

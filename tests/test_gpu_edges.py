@@ -204,3 +204,32 @@ def test_trailing_null_rows_beyond_num_rows_are_tolerated(ctx):
         capi.execute(plan, ctx)
     with pytest.raises(RuntimeError, match="row_idx"):
         _oracle.execute(plan)
+
+
+@pytest.mark.parametrize("bits,probe_dt", [(17, pl.INT64), (18, pl.INT32), (21, pl.INT64)])
+def test_tagged_table_path_forced_bits(bits, probe_dt):
+    """One key word + two-word build carry with >= 17 radix bits takes the "tagged" LDS table
+    ({tag16 | build index} slots + dense carries, k_join TG=1).  Duplicate build keys (the
+    re-walk that emits every further match), NULL keys, a hot probe key (heavy-task path) and
+    misses, against the oracle."""
+    c = capi.Context(radix_bits=bits)
+    try:
+        rng = np.random.default_rng(500 + bits)
+        nb, npr = 300_000, 700_000
+        bk = rng.integers(0, 200_000, nb).astype(np.int32)  # ~1.5 copies per key
+        bk[:40] = 77  # one key with 40+ copies: chains across buckets
+        pk = rng.integers(0, 230_000, npr).astype(np.int32)
+        pk[rng.random(npr) < 0.08] = 77
+        bt = pl.make_table([(pl.INT32, bk, rng.random(nb) > 0.02), (pl.INT64, rng.integers(-(2**62), 2**62, nb).astype(np.int64))])
+        pv = rng.integers(-(2**62), 2**62, npr).astype(np.int64) if probe_dt == pl.INT64 else rng.integers(-(2**31), 2**31 - 1, npr).astype(np.int32)
+        pt = pl.make_table([(pl.INT32, pk, rng.random(npr) > 0.01), (probe_dt, pv)])
+        for build_left in (True, False):
+            if build_left:
+                plan = join2(bt, pt, True, 0, 0, [(0, pl.INT32), (1, pl.INT64)], [(0, pl.INT32), (1, probe_dt)],
+                             [(0, pl.INT32), (1, pl.INT64), (3, probe_dt)])
+            else:
+                plan = join2(pt, bt, False, 0, 0, [(0, pl.INT32), (1, probe_dt)], [(0, pl.INT32), (1, pl.INT64)],
+                             [(3, pl.INT64), (1, probe_dt), (2, pl.INT32)])
+            check(c, plan, small=False)
+    finally:
+        c.destroy()
