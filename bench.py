@@ -274,7 +274,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # RJ_BENCH_FORCE_DIST=1: run the sharded path at world size 1 (rehearsal on a one-GPU box,
+    # under `python -m torch.distributed.run --nproc-per-node 1`)
+    distributed = world > 1 or os.environ.get("RJ_BENCH_FORCE_DIST") == "1"
     if args.gpus != world and distributed:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():

@@ -100,20 +100,44 @@ typedef struct rj_plan {
  * rj_context_destroy ↔ Contest::destroy_context() (src/execute.cpp:330)      */
 typedef struct rj_context rj_context;
 
+/* Multi-GPU (no reference counterpart: the reference is one CPU process).
+ * A context may own several devices of this process (`devices`), and/or be one member of a job
+ * that spans several processes (`world_size` > number of local devices, one process per GPU as
+ * under torchrun).  Every device is one RANK of the job; a sharded join partitions both inputs
+ * by key hash, re-distributes them with ONE all-to-all and joins locally on every rank.
+ * The exchange runs over direct peer copies (all ranks in this process) or RCCL (several
+ * processes; the communicator is created from `comm_id`, which one process makes with
+ * rj_comm_id_create and hands to all others through any channel it likes).               */
+#define RJ_COMM_ID_BYTES 128
+typedef struct rj_comm_id { char bytes[RJ_COMM_ID_BYTES]; } rj_comm_id;
+int rj_comm_id_create(rj_comm_id* out);
+
+enum { RJ_EXCHANGE_AUTO = 0, RJ_EXCHANGE_P2P = 1, RJ_EXCHANGE_RCCL = 2 };
+
 typedef struct rj_config {
-    int32_t  device;      /* HIP device ordinal; -1 = current device          */
+    int32_t  device;      /* HIP device ordinal; -1 = current device (ignored when n_devices > 0) */
     int32_t  profile;     /* 1: HIP events around the data-moving kernels,
                              2: around every launch; 0: none                   */
-    void*    stream;      /* hipStream_t to launch on; NULL = library-owned   */
+    void*    stream;      /* hipStream_t to launch on; NULL = library-owned (single device only) */
     int32_t  radix_bits;  /* total radix bits; 0 = auto from build cardinality */
+    int32_t  n_devices;   /* 0 or 1: one device (`device`); N > 1: this context owns devices[0..N) */
+    const int32_t* devices;   /* [n_devices] HIP ordinals; an ordinal may repeat (virtual ranks
+                                 on one GPU: tests on a single-GPU box)                       */
+    int32_t  world_size;  /* ranks of the whole job; 0 = the local devices only               */
+    int32_t  rank_base;   /* global rank of the first local device (local device i = rank_base+i) */
+    const rj_comm_id* comm_id;  /* required when world_size > local devices                  */
+    int32_t  exchange;    /* RJ_EXCHANGE_*                                                     */
     int32_t  reserved0;
-    uint64_t reserved1;
 } rj_config;
 
 int         rj_context_create(rj_context** out, const rj_config* cfg /* may be NULL */);
 void        rj_context_destroy(rj_context* ctx);
 const char* rj_last_error(const rj_context* ctx); /* ctx may be NULL: last create error */
 int         rj_abi_version(void);
+/* Local devices of a context and the per-device context of each (owned by `ctx`; valid for all
+ * single-device entry points: tables are uploaded / adopted and results fetched per device).  */
+uint32_t    rj_context_n_devices(const rj_context* ctx);
+rj_context* rj_context_device(rj_context* ctx, uint32_t i);
 
 /* ---------------------------------------------------------------- tables --
  * A device-resident ColumnarTable: the Page images of every fixed-width
@@ -161,12 +185,24 @@ const void* rj_result_device_pages(const rj_result* r, uint64_t col);
 void     rj_result_free(rj_result* r);
 
 /* ------------------------------------------------------- sharded (multi-GPU)
- * One process per GPU.  The join shards by hash of the key: rank r owns the
- * tuples whose hash digit == r.  Stage A runs locally on every rank, the
- * caller exchanges the per-destination slices with one all-to-all (RCCL via
- * torch.distributed in bench.py / pyrj.dist), stage B joins what arrived.
- * Tuples are SoA: `key` (int32) plus `carry` (one 32-bit word per tuple, the
- * payload or a row id).                                                      */
+ * rj_execute on a context that owns several devices shards every JoinNode it can across them
+ * (inputs are split by row ranges on the way up, the result is the concatenation of the ranks'
+ * pages) and falls back to the first device for plans it cannot shard — the drop-in boundary
+ * stays Contest::execute.
+ *
+ * rj_execute_sharded is the resident form (bench.py, one process per GPU or one process with
+ * several): tables[d * n_inputs + i] is the shard of plan input i that lives on local device d
+ * (made with rj_table_upload / rj_table_adopt_device on rj_context_device(ctx, d)); the union of
+ * all ranks' shards is the input.  out[d] receives local device d's slice of the result (rows
+ * whose key hashes to that rank).  Collective: every process of the job must call it with the
+ * same plan.  Shardable plans: every JoinNode carries at most one fixed-width non-key column per
+ * side (the BASELINE shape); others return RJ_ERR_UNSUPPORTED.                              */
+int rj_execute_sharded(rj_context* ctx, const rj_plan* plan, rj_table* const* tables,
+                       uint64_t n_inputs, int32_t flags, rj_result** out /* [n local devices] */);
+
+/* Lower-level pieces of the same path, for callers that run the exchange themselves (e.g.
+ * torch.distributed in pyrj.dist, gloo on CPU in the tests).  Tuples are SoA: `key` (int32)
+ * plus `carry` (one 32-bit word per tuple, the payload or a row id).                         */
 typedef struct rj_tuples {
     uint64_t n;
     void*    key;    /* device, n * 4 bytes  */
@@ -189,7 +225,8 @@ int  rj_shard_partition(rj_context* ctx, const rj_table* t, uint64_t key_col,
 /* Stage B: inner equi-join of two tuple sets resident in HBM (caller-owned
  * device pointers).  Output columns: key, build carry, probe carry — i.e. the
  * plan Join(build_left=true, out={0,1,3}) over Scan{key,payload} children.
- * skip_rank_bits = log2(n_ranks) hash bits already consumed by stage A.      */
+ * skip_rank_bits = log2(n_ranks) top hash bits already consumed by stage A (they are constant
+ * on this rank: the radix plan stays below them).                                           */
 int  rj_join_tuples(rj_context* ctx, const rj_tuples* build, const rj_tuples* probe,
                     uint32_t skip_rank_bits, int32_t flags, rj_result** out);
 

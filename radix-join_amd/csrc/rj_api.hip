@@ -30,7 +30,7 @@ static int guarded(rj_context* ctx, F&& f) {
 
 extern "C" {
 
-int rj_abi_version(void) { return 1; }
+int rj_abi_version(void) { return 2; }
 
 int rj_context_create(rj_context** out, const rj_config* cfg) {
     if (!out) return RJ_ERR_ARG;
@@ -44,23 +44,50 @@ int rj_context_create(rj_context** out, const rj_config* cfg) {
             throw rj::Error(RJ_ERR_NO_GPU,
                             "no HIP device: librj has no CPU fallback (the GPU path is the product)");
         }
-        std::unique_ptr<rj_context> c(new rj_context());
-        int dev = cfg ? cfg->device : -1;
-        if (dev < 0) RJ_HIP(hipGetDevice(&dev));
-        if (dev >= n_dev) throw rj::Error(RJ_ERR_ARG, "device ordinal out of range");
-        RJ_HIP(hipSetDevice(dev));
-        c->device = dev;
-        if (cfg && cfg->stream) {
-            c->stream = static_cast<hipStream_t>(cfg->stream);
+        // one lane (single-device context) per local device; lane 0 is the handle
+        std::vector<int> devs;
+        if (cfg && cfg->n_devices > 0) {
+            if (!cfg->devices) throw rj::Error(RJ_ERR_ARG, "n_devices > 0 but devices is NULL");
+            for (int i = 0; i < cfg->n_devices; ++i) devs.push_back(cfg->devices[i]);
         } else {
-            RJ_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-            c->own_stream = true;
+            int dev = cfg ? cfg->device : -1;
+            if (dev < 0) RJ_HIP(hipGetDevice(&dev));
+            devs.push_back(dev);
         }
-        c->prof.on = cfg && cfg->profile;
-        c->prof.level = cfg && cfg->profile >= 2 ? 2 : 1;
-        c->prof.stream = c->stream;
-        c->radix_bits_override = cfg ? cfg->radix_bits : 0;
-        c->tune.from_env();
+        if (devs.size() > 1 && cfg->stream)
+            throw rj::Error(RJ_ERR_ARG, "a caller-provided stream needs a single-device context");
+        auto make_lane = [&](int dev, bool first) {
+            if (dev < 0 || dev >= n_dev) throw rj::Error(RJ_ERR_ARG, "device ordinal out of range");
+            std::unique_ptr<rj_context> c(new rj_context());
+            RJ_HIP(hipSetDevice(dev));
+            c->device = dev;
+            if (first && cfg && cfg->stream) {
+                c->stream = static_cast<hipStream_t>(cfg->stream);
+            } else {
+                RJ_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+                c->own_stream = true;
+            }
+            c->prof.on = cfg && cfg->profile;
+            c->prof.level = cfg && cfg->profile >= 2 ? 2 : 1;
+            c->prof.stream = c->stream;
+            c->radix_bits_override = cfg ? cfg->radix_bits : 0;
+            c->tune.from_env();
+            return c;
+        };
+        std::unique_ptr<rj_context> c = make_lane(devs[0], true);
+        for (size_t i = 1; i < devs.size(); ++i) {
+            rj_context* p = make_lane(devs[i], false).release();
+            p->group = c.get();
+            c->peers.push_back(p);
+        }
+        const int world = cfg && cfg->world_size > 0 ? cfg->world_size : (int)devs.size();
+        if (world > 1 || (cfg && cfg->exchange != RJ_EXCHANGE_AUTO)) {
+            std::vector<Context*> lanes;
+            for (int i = 0; i < c->n_lanes(); ++i) lanes.push_back(c->lane(i));
+            c->comm.reset(new Comm(lanes, world, cfg ? cfg->rank_base : 0, cfg ? cfg->exchange : 0,
+                                   cfg ? cfg->comm_id : nullptr));
+        }
+        RJ_HIP(hipSetDevice(devs[0]));
         *out = c.release();
     } catch (const rj::Error& e) {
         code = e.code;
@@ -79,6 +106,25 @@ int rj_context_create(rj_context** out, const rj_config* cfg) {
 void rj_context_destroy(rj_context* ctx) {
     if (!ctx) return;
     delete ctx;
+}
+
+uint32_t rj_context_n_devices(const rj_context* ctx) { return ctx ? (uint32_t)ctx->n_lanes() : 0; }
+
+rj_context* rj_context_device(rj_context* ctx, uint32_t i) {
+    if (!ctx || i >= (uint32_t)ctx->n_lanes()) return nullptr;
+    return static_cast<rj_context*>(ctx->lane((int)i));
+}
+
+int rj_comm_id_create(rj_comm_id* out) {
+    if (!out) return RJ_ERR_ARG;
+    try {
+        Comm::make_id(out);
+        return RJ_OK;
+    } catch (const std::exception& e) {
+        std::lock_guard<std::mutex> g(g_err_mu);
+        g_create_error = e.what();  // rj_last_error(NULL)
+        return RJ_ERR_DEVICE;
+    }
 }
 
 const char* rj_last_error(const rj_context* ctx) {
@@ -222,6 +268,21 @@ const void* rj_result_device_pages(const rj_result* r, uint64_t c) {
 }
 
 void rj_result_free(rj_result* r) { delete r; }
+
+int rj_execute_sharded(rj_context* ctx, const rj_plan* plan, rj_table* const* tables,
+                       uint64_t n_inputs, int32_t flags, rj_result** out) {
+    if (!ctx || !plan || !out || (n_inputs && !tables)) return RJ_ERR_ARG;
+    const int nl = ctx->n_lanes();
+    for (int l = 0; l < nl; ++l) out[l] = nullptr;
+    return guarded(ctx, [&] {
+        if (ctx->group) throw rj::Error(RJ_ERR_ARG, "rj_execute_sharded wants the group context, not one of its devices");
+        std::vector<Table*>  ts((size_t)nl * n_inputs);
+        for (size_t i = 0; i < ts.size(); ++i) ts[i] = tables[i];
+        std::vector<Result*> rs((size_t)nl, nullptr);
+        execute_sharded(ctx, plan, ts.data(), n_inputs, flags, rs.data());
+        for (int l = 0; l < nl; ++l) out[l] = static_cast<rj_result*>(rs[l]);
+    });
+}
 
 int rj_shard_partition(rj_context* ctx, const rj_table* t, uint64_t key_col, uint64_t carry_col,
                        uint32_t n_ranks, rj_tuples* out, uint64_t* counts) {

@@ -1,0 +1,73 @@
+// rj_comm.hpp — the one exchange step of a sharded join: a variable-size all-to-all between the
+// ranks of a job (one rank per GPU), plus the tiny all-gather of counts that sizes it.
+//
+// Two transports behind one interface:
+//   P2P   every rank lives in THIS process (one context owning N devices): slices move with
+//         hipMemcpyPeerAsync, one copy per (source, destination) pair, all pairs in flight at
+//         once — on MI355X every pair of GPUs has its own xGMI link, so the all-to-all is not
+//         ring-bound;
+//   RCCL  ranks live in several processes (one process per GPU, e.g. bench.py under torchrun):
+//         grouped ncclSend/ncclRecv on a communicator created from an rj_comm_id (= ncclUniqueId)
+//         the host program passed to every rank.  librccl is dlopen'ed on first use, so a
+//         single-GPU deployment never loads it (and a process that already holds PyTorch's copy
+//         binds to that one through the shared soname).
+// There is no reference counterpart (the reference is one CPU process).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+#include "../../include/rj.h"
+
+namespace rj {
+
+struct Context;
+
+// One local rank's half of an all-to-all of bytes.
+struct XferSpec {
+    const uint8_t*        send = nullptr;  // device memory of the local rank
+    std::vector<uint64_t> send_off, send_cnt;  // [world] bytes, per destination rank
+    uint8_t*              recv = nullptr;  // device memory of the local rank
+    std::vector<uint64_t> recv_off, recv_cnt;  // [world] bytes, per source rank
+};
+
+class Comm {
+   public:
+    enum Mode { P2P = 1, RCCL = 2 };
+    // lanes: the contexts of the local ranks (rank_base + i); world = ranks of the whole job
+    Comm(std::vector<Context*> lanes, int world, int rank_base, int mode, const rj_comm_id* id);
+    ~Comm();
+    int  world() const { return world_; }
+    int  rank_base() const { return rank_base_; }
+    int  n_local() const { return (int)lanes_.size(); }
+    Mode mode() const { return mode_; }
+
+    // vals[l][0..k) of every local rank l  ->  all[r][0..k) for every rank r of the job.
+    // Synchronises the host with the exchange streams.
+    void allgather_u64(const std::vector<std::vector<uint64_t>>& vals, size_t k,
+                       std::vector<std::vector<uint64_t>>& all);
+
+    // One all-to-all: specs[l] = local rank l's slices.  Enqueued on the exchange streams, which
+    // first wait for `ready[l]` (recorded on lane l's compute stream once its send buffer is
+    // complete).  On return done[l] has been recorded: lane l's recv buffer is complete when it
+    // fires.  Buffers must stay alive until then.
+    void all_to_all(const std::vector<XferSpec>& specs, const std::vector<hipEvent_t>& ready,
+                    std::vector<hipEvent_t>& done);
+
+    hipStream_t xfer_stream(int lane) const { return xfer_[lane]; }
+
+    static void make_id(rj_comm_id* out);  // ncclGetUniqueId
+
+   private:
+    std::vector<Context*>    lanes_;
+    int                      world_ = 1, rank_base_ = 0;
+    Mode                     mode_ = P2P;
+    std::vector<hipStream_t> xfer_;
+    std::vector<void*>       nccl_;       // ncclComm_t per local rank (RCCL mode)
+    std::vector<void*>       cnt_dev_;    // per lane: small device buffer for count all-gathers
+    std::vector<hipEvent_t>  sent_;       // P2P: per lane, "all my outgoing copies are enqueued and done"
+    size_t                   cnt_cap_ = 0;
+};
+
+}  // namespace rj

@@ -202,6 +202,11 @@ void* Context::upload_staging(size_t bytes) {
 }
 
 Context::~Context() {
+    // the exchange transport references the lanes: it goes first, then the lanes themselves
+    comm.reset();
+    for (Context* p : peers) delete static_cast<rj_context*>(p);
+    peers.clear();
+    (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
     if (copy_stream) {
         (void)hipStreamSynchronize(copy_stream);

@@ -46,6 +46,16 @@ struct Parted {
     uint32_t NP = 0;
     std::vector<uint32_t> pbits;  // radix bits of each pass
     bool     packed = false;      // w[0] = {hashed key, carry} pairs, no w[1]
+    uint64_t n_tuples = 0;        // tuples that went in (NULL keys are dropped on the way: an upper bound)
+};
+
+// Tuples that already sit in the partition layout (hashed word arrays, a pair array for a
+// two-word carry, or one array of packed {key, carry} pairs): what a rank holds after the
+// exchange step of a sharded join.
+struct WordSrc {
+    Words    w{};
+    uint64_t n = 0;
+    bool     packed = false;
 };
 
 struct JoinSpec {
@@ -135,7 +145,7 @@ class Exec {
         Words    ext{};
         ext.w[0] = static_cast<uint32_t*>(out->key);
         ext.w[1] = static_cast<uint32_t*>(out->carry);
-        Parted P = partition(src, 1, 1, rb, /*shift0=*/rb ? 32 - rb : 31, /*single pass*/ true, &ext);
+        Parted P = partition(&src, nullptr, 1, 1, rb, /*shift0=*/rb ? 32 - rb : 31, /*single pass*/ true, &ext);
         std::vector<uint32_t> off(n_ranks + 1);
         RJ_HIP(hipMemcpyAsync(off.data(), P.off->p, (n_ranks + 1) * 4, hipMemcpyDeviceToHost,
                               ctx->stream));
@@ -146,7 +156,7 @@ class Exec {
         out->reserved = 0;
     }
 
-   private:
+    // ---- state and building blocks (a ShardedExec drives one Exec per rank through them)
     Context*       ctx;
     const rj_plan* plan;
     Table* const*  tables;
@@ -170,6 +180,10 @@ class Exec {
             return d;
         }
         d.width = tc.type == RJ_INT32 ? 4 : 8;
+        if (t->num_rows == 0) {  // nothing to address (an empty shard): no validity to carry either
+            d.kind = COL_DENSE;
+            return d;
+        }
         if (tc.regular) {
             d.kind = COL_PAGED;
             d.ptr = tc.dev_pages;
@@ -282,12 +296,16 @@ class Exec {
         return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(k, 1), 8);
     }
 
+    // Source = columns (`src`: page decode, NULL drop and hashing ride on the first pass) or
+    // tuples already in the partition layout (`ws`, sharded stage B).
     // `external`: caller-owned arrays that receive the output of a single-pass partition
-    Parted partition(const TupleSrc& src, int KW, int CW, uint32_t bits, uint32_t shift0 = 0,
-                     bool single_pass = false, const Words* external = nullptr) {
+    Parted partition(const TupleSrc* srcp, const WordSrc* ws, int KW, int CW, uint32_t bits,
+                     uint32_t shift0 = 0, bool single_pass = false, const Words* external = nullptr) {
         Parted P;
         P.NW = KW + CW;
-        const uint64_t n = src.n_rows;
+        const TupleSrc none{};
+        const TupleSrc& src = srcp ? *srcp : none;
+        const uint64_t  n = ws ? ws->n : src.n_rows;
         uint32_t       passes = single_pass ? 1 : (bits + PT_MAXBITS - 1) / PT_MAXBITS;
         if (passes == 0) passes = 1;
         std::vector<uint32_t> pbits(passes, bits / passes);
@@ -310,7 +328,8 @@ class Exec {
         // bytes per run); RJ_TUNE_PACK: 0 = never, 1 = every plan, 2 = fine-histogram plans only
         // (a later pass' plain histogram reads 8 instead of 4 bytes per tuple from pairs)
         const int pack_mode = ctx->tune.pack;
-        P.packed = !external && KW == 1 && CW == 1 && (pack_mode == 1 || (pack_mode == 2 && fine));
+        P.packed = ws ? ws->packed
+                      : (!external && KW == 1 && CW == 1 && (pack_mode == 1 || (pack_mode == 2 && fine)));
         BufP  A[MAX_WORDS], B[MAX_WORDS];
         Words wa{}, wb{};
         for (int a = 0; a < (P.packed ? 1 : P.NW); ++a) {
@@ -331,7 +350,7 @@ class Exec {
         }
         BufP     seg_off;  // offsets produced by the previous pass
         uint32_t nseg = 1, shift = shift0;
-        Words    cur{}, nxt = wa;
+        Words    cur = ws ? ws->w : Words{}, nxt = wa;
         bool     cur_is_a = false;
         BufP       fine_off, fine_cursor, coarse_off, coarse_cursor;
         if (fine) {
@@ -343,9 +362,12 @@ class Exec {
             coarse_cursor = ctx->buf((uint64_t)F1 * 4);
             RJ_HIP(hipMemsetAsync(fh->p, 0, (uint64_t)NB * 4, ctx->stream));
             const uint64_t tiles = (n + PT_TILE - 1) / PT_TILE;
-            launch_fine_hist_src(L, src, KW, shift0, pbits[0], pbits[1],
-                                 (uint32_t)std::min<uint64_t>(tiles, (uint64_t)ctx->compute_units()),
-                                 fh->as<uint32_t>());
+            const uint32_t fgrid = (uint32_t)std::min<uint64_t>(tiles, (uint64_t)ctx->compute_units());
+            if (ws)
+                launch_fine_hist_words(L, ws->w, ws->packed, (uint32_t)n, shift0, pbits[0], pbits[1], fgrid,
+                                       fh->as<uint32_t>());
+            else
+                launch_fine_hist_src(L, src, KW, shift0, pbits[0], pbits[1], fgrid, fh->as<uint32_t>());
             launch_scan_fine(L, fh->as<uint32_t>(), F1, F2, fine_off->as<uint32_t>(),
                              fine_cursor->as<uint32_t>(), coarse_off->as<uint32_t>(),
                              coarse_cursor->as<uint32_t>());
@@ -387,7 +409,7 @@ class Exec {
                     RJ_HIP(hipMemsetAsync(hist->p, 0, bins * 4, ctx->stream));
                     pp.hist = hist->as<uint32_t>();
                     pp.cursor = cursor->as<uint32_t>();
-                    if (p == 0)
+                    if (p == 0 && !ws)
                         launch_pass_hist_src(L, src, KW, pp, n_groups);
                     else if (P.packed)
                         launch_pass_hist_packed(L, cur.w[0], pp, n_groups);
@@ -397,11 +419,11 @@ class Exec {
                                          off->as<uint32_t>(), pp.cursor);
                 }
                 if (P.packed) {
-                    if (p == 0)
+                    if (p == 0 && !ws)
                         launch_pass_scatter_src_packed(L, src, pp, n_groups, nxt.w[0]);
                     else
                         launch_pass_scatter_packed(L, cur.w[0], pp, n_groups, nxt.w[0]);
-                } else if (p == 0) {
+                } else if (p == 0 && !ws) {
                     launch_pass_scatter_src(L, src, KW, CW, pp, n_groups, nxt);
                 } else {
                     launch_pass_scatter_dense(L, cur, P.NW, CW == 2 ? KW : -1, pp, n_groups, nxt);
@@ -418,6 +440,7 @@ class Exec {
             P.off = seg_off;
             P.NP = nseg;
             P.pbits = pbits;
+            P.n_tuples = n;
             return P;
         }
 
@@ -459,12 +482,26 @@ class Exec {
             return r;
         }
 
-        // execute_hash_join + hash_join_omp (reference src/execute.cpp:43-282)
-        Rel join_core(Rel& left, Rel& right, const JoinSpec& js, Result* root_res) {
+        // What a JoinNode decides before any tuple moves: key type, which columns each side
+        // must deliver and how they travel (execute_hash_join, reference src/execute.cpp:266-282,
+        // and the head of hash_join_omp, :43-83).
+        struct JoinState {
+            Side     ls, rs;
+            bool     build_left = true, is_root = false, f64 = false, need_key_stream = false;
+            bool     type_mismatch = false;  // probe key of another type: no row can match (:65-71)
+            size_t   lw = 0, rw = 0;
+            int      KW = 1;
+            uint64_t cap_hint = 0;  // rows the output streams are sized for at the first attempt
+            Side&    bs() { return build_left ? ls : rs; }
+            Side&    ps() { return build_left ? rs : ls; }
+        };
+
+        void join_prepare(Rel& left, Rel& right, const JoinSpec& js, bool is_root, JoinState& st) {
             const size_t lw = left.cols.size(), rw = right.cols.size();
-            const bool   is_root = root_res != nullptr;
-            // with an empty child the reference returns {} before looking at anything (:50)
-            if (left.n == 0 || right.n == 0) return empty_rel(js, root_res);
+            st.lw = lw;
+            st.rw = rw;
+            st.is_root = is_root;
+            st.build_left = js.build_left;
             if (js.left_attr >= lw || js.right_attr >= rw)
                 throw_fmt(RJ_ERR_ARG, "join: key attr out of range");
             for (size_t k = 0; k < js.out_idx.size(); ++k) {
@@ -474,36 +511,31 @@ class Exec {
                 if (c.type != js.out_type[k])
                     throw_fmt(RJ_ERR_ARG, "join: declared type differs from the child column's type");
             }
-            Side  ls, rs;
+            Side &ls = st.ls, &rs = st.rs;
             ls.rel = &left;
             ls.key_col = js.left_attr;
             rs.rel = &right;
             rs.key_col = js.right_attr;
-            Side&       bs = js.build_left ? ls : rs;
-            Side&       ps = js.build_left ? rs : ls;
-            const DCol& bk = bs.rel->cols[bs.key_col];
-            const DCol& pk = ps.rel->cols[ps.key_col];
+            const DCol& bk = st.bs().rel->cols[st.bs().key_col];
+            const DCol& pk = st.ps().rel->cols[st.ps().key_col];
             // KeyType = build side's key type (:271-273)
             if (bk.type == RJ_VARCHAR)
                 throw_fmt(RJ_ERR_UNSUPPORTED,
                           "VARCHAR join keys are not supported on the GPU path (never a JOB join key)");
             if (bk.type < RJ_INT32 || bk.type > RJ_VARCHAR) throw_fmt(RJ_ERR_ARG, "Unsupported join type");
             // probe values of another variant alternative are never valid (:65-71)
-            if (pk.type != bk.type) return empty_rel(js, root_res);
-            const int  KW = bk.type == RJ_INT32 ? 1 : 2;
-            const bool f64 = bk.type == RJ_FP64;
+            st.type_mismatch = pk.type != bk.type;
+            st.KW = bk.type == RJ_INT32 ? 1 : 2;
+            st.f64 = bk.type == RJ_FP64;
             // matching keys are bit-identical on both sides (FP64 included: bit-pattern equality,
-            // see SrcLoader::key2), so one emitted key stream serves either side's key column
-            const bool key_stream_ok = true;
-
-            // which child columns must each side deliver?
-            bool need_key_stream = false;
+            // see SrcLoader::key2), so one emitted key stream serves either side's key column.
+            // Which child columns must each side deliver?
             for (size_t k = 0; k < js.out_idx.size(); ++k) {
                 bool  is_left = js.out_idx[k] < lw;
                 Side& s = is_left ? ls : rs;
                 int   c = (int)(is_left ? js.out_idx[k] : js.out_idx[k] - lw);
-                if (key_stream_ok && (uint64_t)c == s.key_col)
-                    need_key_stream = true;
+                if ((uint64_t)c == s.key_col)
+                    st.need_key_stream = true;
                 else
                     s.need.insert(c);
             }
@@ -520,49 +552,84 @@ class Exec {
                     s->CW = 1;
                 }
             }
+            st.cap_hint = std::max(left.n, right.n);
+        }
 
-            // radix bit plan from the build cardinality
-            uint32_t bits = js.forced_bits > 0
-                                ? (uint32_t)js.forced_bits
-                                : ceil_log2((bs.rel->n + JN_TARGET_BUILD - 1) / JN_TARGET_BUILD);
+        // radix bit plan from the build cardinality; `top_bits_taken` high hash bits are constant
+        // on this rank (a sharded join's rank digit): the plan stays below them
+        uint32_t join_bits(const JoinSpec& js, uint64_t build_n, uint32_t top_bits_taken = 0) {
+            uint32_t bits = js.forced_bits > 0 ? (uint32_t)js.forced_bits
+                                               : ceil_log2((build_n + JN_TARGET_BUILD - 1) / JN_TARGET_BUILD);
             // a third pass costs 20 B/tuple more than slightly fuller tables: stay at two passes
             // (2 * PT_MAXBITS bits) while the mean build partition still fits the LDS table with
             // a margin (rare larger partitions are joined in table-sized chunks anyway)
             if (js.forced_bits <= 0 && bits > 2 * PT_MAXBITS &&
-                (bs.rel->n >> (2 * PT_MAXBITS)) <= (uint64_t)(JN_RMAX * 0.95))
+                (build_n >> (2 * PT_MAXBITS)) <= (uint64_t)(JN_RMAX * 0.95))
                 bits = 2 * PT_MAXBITS;
             bits = std::min<uint32_t>(std::max<uint32_t>(bits, 1), 27);
+            if (top_bits_taken && bits > 32 - top_bits_taken) bits = 32 - top_bits_taken;
+            return bits;
+        }
+
+        TupleSrc make_src(const JoinState& st, const Side& s, const JoinSpec& js) {
+            TupleSrc src{};
+            src.key = s.rel->cols[s.key_col].ref();
+            src.n_rows = (uint32_t)s.rel->n;
+            src.carry_mode = s.carry_mode;
+            if (s.carry_mode == CARRY_COLUMN) {
+                src.carry = s.rel->cols[s.carry_col].ref();
+                // a base table's row-id column (VARCHAR stand-in) IS the row index
+                if (src.carry.kind == COL_IOTA) src.carry_mode = CARRY_ROWIDX;
+            }
+            src.key_f64 = st.f64 ? 1 : 0;
+            src.prehashed = js.prehashed ? 1 : 0;
+            return src;
+        }
+
+        // execute_hash_join + hash_join_omp (reference src/execute.cpp:43-282) on one device
+        Rel join_core(Rel& left, Rel& right, const JoinSpec& js, Result* root_res) {
+            // with an empty child the reference returns {} before looking at anything (:50)
+            if (left.n == 0 || right.n == 0) return empty_rel(js, root_res);
+            JoinState st;
+            join_prepare(left, right, js, root_res != nullptr, st);
+            if (st.type_mismatch) return empty_rel(js, root_res);
+            Side&          bs = st.bs();
+            Side&          ps = st.ps();
+            const uint32_t bits = join_bits(js, bs.rel->n);
             if (ctx->tune.diag >= 2)
                 fprintf(stderr, "[rj diag] join build=%llu probe=%llu bits=%u cw=%d/%d\n",
                         (unsigned long long)bs.rel->n, (unsigned long long)ps.rel->n, bits, bs.CW, ps.CW);
-
-            auto make_src = [&](Side& s) {
-                TupleSrc src{};
-                src.key = s.rel->cols[s.key_col].ref();
-                src.n_rows = (uint32_t)s.rel->n;
-                src.carry_mode = s.carry_mode;
-                if (s.carry_mode == CARRY_COLUMN) {
-                    src.carry = s.rel->cols[s.carry_col].ref();
-                    // a base table's row-id column (VARCHAR stand-in) IS the row index
-                    if (src.carry.kind == COL_IOTA) src.carry_mode = CARRY_ROWIDX;
-                }
-                src.key_f64 = f64 ? 1 : 0;
-                src.prehashed = js.prehashed ? 1 : 0;
-                return src;
-            };
             // A build side that fits one LDS table is not partitioned at all: every workgroup builds
             // the same table and streams a slice of the probe child past it (k_join_bcast)
             const bool bcast = bs.rel->n <= (uint64_t)JN_RMAX && js.forced_bits <= 0 && !js.prehashed &&
                                ctx->tune.bcast != 0;
-            Parted   PB, PP;
+            Parted PB, PP;
+            if (!bcast) {
+                TupleSrc sb = make_src(st, bs, js), sp = make_src(st, ps, js);
+                PB = partition(&sb, nullptr, st.KW, bs.CW, bits);
+                PP = partition(&sp, nullptr, st.KW, ps.CW, bits);
+            }
+            return join_finish(st, js, bcast ? nullptr : &PB, bcast ? nullptr : &PP, bits, root_res);
+        }
+
+        // Build + probe over co-partitioned tuples (PB / PP; nullptr = broadcast join straight
+        // from the children's columns), output streams, late materialisation, result pages.
+        Rel join_finish(JoinState& st, const JoinSpec& js, const Parted* PBp, const Parted* PPp,
+                        uint32_t bits, Result* root_res) {
+            Side &         ls = st.ls, &rs = st.rs, &bs = st.bs(), &ps = st.ps();
+            const size_t   lw = st.lw;
+            const bool     is_root = st.is_root, bcast = PBp == nullptr;
+            const int      KW = st.KW;
+            const bool     need_key_stream = st.need_key_stream;
+            const uint64_t probe_n = bcast ? ps.rel->n : (uint64_t)0;
+            (void)probe_n;
             uint32_t max_tasks = 0;
             BufP     tasks;
             BufP     counters = ctx->buf(16);  // [0..7] out cursor (u64), [8..11] n_heavy
             if (!bcast) {
-                PB = partition(make_src(bs), KW, bs.CW, bits);
-                PP = partition(make_src(ps), KW, ps.CW, bits);
+                const Parted &PB = *PBp, &PP = *PPp;
                 // heavy probe partitions -> task list
-                max_tasks = (uint32_t)(2 * (ps.rel->n / JN_HEAVY) + 2);
+                max_tasks = (uint32_t)(2 * (PP.n_tuples / JN_HEAVY) + 2);
                 tasks = ctx->buf((uint64_t)max_tasks * 12);
                 launch_heavy_tasks_zeroed(PB, PP, tasks, counters, max_tasks);
             }
@@ -593,7 +660,7 @@ class Exec {
                 }
             }
 
-            uint64_t cap = std::max(left.n, right.n);
+            uint64_t cap = st.cap_hint;
             cap = std::min<uint64_t>(cap + 1024, 0xfffffff0ull);
             BufP            key_stream;
             uint64_t        nrows = 0;
@@ -606,8 +673,8 @@ class Exec {
                 RJ_HIP(hipMemsetAsync(counters->p, 0, 8, ctx->stream));
                 if (bcast) {
                     BcastParams bp{};
-                    bp.R = make_src(bs);
-                    bp.S = make_src(ps);
+                    bp.R = make_src(st, bs, js);
+                    bp.S = make_src(st, ps, js);
                     bp.key = OutStream{key_stream ? key_stream->as<uint8_t>() : nullptr, key_mode, 0};
                     bp.bc = OutStream{bs.stream ? bs.stream->as<uint8_t>() : nullptr, bs.stream_mode, 0};
                     bp.pc = OutStream{ps.stream ? ps.stream->as<uint8_t>() : nullptr, ps.stream_mode, 0};
@@ -617,6 +684,7 @@ class Exec {
                     launch_join_bcast(L, KW, bs.CW, ps.CW, bp,
                                       (uint32_t)std::min<uint64_t>(chunks, (uint64_t)ctx->compute_units() * 8));
                 } else {
+                const Parted &PB = *PBp, &PP = *PPp;
                 JoinParams jp{};
                 jp.R = PB.w;
                 jp.S = PP.w;
@@ -708,7 +776,7 @@ class Exec {
             BufP buf;           // where this column's values/pages live
             int  buf_mode = ST_NONE;
             BufP valid;
-            if (key_stream_ok && (uint64_t)c == s.key_col) {
+            if ((uint64_t)c == s.key_col) {
                 buf = key_stream;
                 buf_mode = key_mode;
             } else if (s.carry_mode == CARRY_COLUMN) {
@@ -815,6 +883,370 @@ class Exec {
     }
 };
 
+
+// ================================================================ sharded executor
+// One JoinNode across the ranks of a job: every rank
+//   stage A   forms (hashed key, carry) tuples of its shard of both children and partitions
+//             them by OWNER rank = top log2(world) hash bits (one radix pass, fan-out = world);
+//   exchange  ONE variable-size all-to-all per relation (rj_comm: peer copies or RCCL), on its
+//             own stream — the probe side's exchange runs behind the build side's radix passes;
+//   stage B   runs the remaining radix passes + build/probe on what arrived, exactly the
+//             single-device join on prehashed tuples whose top bits are constant.
+// Results stay on the owning rank (no reduction).  One host thread drives all local ranks
+// phase by phase; everything between the count read-backs is asynchronous.
+class ShardedExec {
+   public:
+    ShardedExec(Context* group, const rj_plan* plan, Table* const* tables, uint64_t n_inputs, int flags)
+        : g_(group), plan_(plan), nl_(group->n_lanes()) {
+        if (!plan || plan->root >= plan->n_nodes) throw_fmt(RJ_ERR_ARG, "bad plan root");
+        comm_ = group->comm.get();
+        world_ = comm_ ? comm_->world() : 1;
+        rank_base_ = comm_ ? comm_->rank_base() : 0;
+        rb_ = ceil_log2((uint64_t)world_);
+        for (int l = 0; l < nl_; ++l) {
+            Context* c = group->lane(l);
+            for (uint64_t i = 0; i < n_inputs; ++i) {
+                Table* t = tables[(size_t)l * n_inputs + i];
+                if (!t) throw_fmt(RJ_ERR_ARG, "null table");
+                if (t->ctx != c) throw_fmt(RJ_ERR_ARG, "table %llu of device %d lives on another device's context",
+                                           (unsigned long long)i, l);
+            }
+            ex_.emplace_back(new Exec(c, plan, tables + (size_t)l * n_inputs, n_inputs, flags));
+        }
+    }
+
+    void run(Result** out) {
+        std::vector<std::unique_ptr<Result>> res;
+        for (int l = 0; l < nl_; ++l) {
+            res.emplace_back(new rj_result());
+            res.back()->ctx = g_->lane(l);
+        }
+        std::vector<Result*> rp;
+        for (auto& r : res) rp.push_back(r.get());
+        const rj_node& root = plan_->nodes[plan_->root];
+        try {
+            if (root.kind == RJ_NODE_SCAN) {
+                for (int l = 0; l < nl_; ++l) {
+                    use(l);
+                    ex_[l]->root_scan(root, *res[l]);
+                }
+            } else {
+                (void)node(plan_->root, &rp, 0);
+            }
+            sync_all();
+        } catch (...) {
+            // kernels and copies still queued may reference buffers about to be released
+            for (int l = 0; l < nl_; ++l) {
+                (void)hipSetDevice(g_->lane(l)->device);
+                (void)hipStreamSynchronize(g_->lane(l)->stream);
+                if (comm_) (void)hipStreamSynchronize(comm_->xfer_stream(l));
+            }
+            (void)hipSetDevice(g_->device);
+            throw;
+        }
+        use(0);
+        for (int l = 0; l < nl_; ++l) out[l] = res[l].release();
+    }
+
+   private:
+    Context*                           g_;
+    const rj_plan*                     plan_;
+    int                                nl_, world_ = 1, rank_base_ = 0;
+    uint32_t                           rb_ = 0;
+    Comm*                              comm_ = nullptr;
+    std::vector<std::unique_ptr<Exec>> ex_;
+
+    void use(int l) { RJ_HIP(hipSetDevice(g_->lane(l)->device)); }
+    void sync_all() {
+        for (int l = 0; l < nl_; ++l) {
+            use(l);
+            g_->lane(l)->sync();
+        }
+    }
+
+    struct Ev {  // RAII event on a lane's device
+        hipEvent_t e = nullptr;
+        Ev() = default;
+        Ev(const Ev&) = delete;
+        Ev& operator=(const Ev&) = delete;
+        void make() { RJ_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
+        ~Ev() {
+            if (e) (void)hipEventDestroy(e);
+        }
+    };
+
+    std::vector<Rel> node(uint64_t idx, std::vector<Result*>* root_res, int depth) {
+        if (idx >= plan_->n_nodes) throw_fmt(RJ_ERR_ARG, "bad node index");
+        if (depth > 4096) throw_fmt(RJ_ERR_ARG, "plan too deep (cycle?)");
+        const rj_node& n = plan_->nodes[idx];
+        if (n.kind == RJ_NODE_SCAN) {
+            std::vector<Rel> r((size_t)nl_);
+            for (int l = 0; l < nl_; ++l) {
+                use(l);
+                r[l] = ex_[l]->scan(n);
+            }
+            return r;
+        }
+        if (n.kind != RJ_NODE_JOIN) throw_fmt(RJ_ERR_ARG, "bad node kind");
+        std::vector<Rel> L = node(n.left, nullptr, depth + 1);
+        std::vector<Rel> R = node(n.right, nullptr, depth + 1);
+        JoinSpec         js;
+        js.build_left = n.build_left != 0;
+        js.left_attr = n.left_attr;
+        js.right_attr = n.right_attr;
+        js.out_idx.assign(n.out_idx, n.out_idx + n.n_out);
+        js.out_type.assign(n.out_type, n.out_type + n.n_out);
+        js.forced_bits = g_->radix_bits_override;
+        return join(L, R, js, root_res);
+    }
+
+    // bytes per tuple of array `a` in the partition layout, 0 = no such array
+    static uint32_t array_width(const Parted& P, int KW, int CW, int a) {
+        if (P.packed) return a == 0 ? 8u : 0u;
+        if (a >= P.NW) return 0;
+        if (CW == 2 && a == KW + 1) return 0;       // second half of the pair array
+        return (CW == 2 && a == KW) ? 8u : 4u;
+    }
+
+    std::vector<Rel> join(std::vector<Rel>& left, std::vector<Rel>& right, const JoinSpec& js,
+                          std::vector<Result*>* root_res) {
+        std::vector<Exec::JoinState> st((size_t)nl_);
+        const bool diag = g_->tune.diag >= 2;
+        auto       t_start = std::chrono::steady_clock::now();
+        auto       lap = [&](const char* what) {
+            if (!diag) return;
+            sync_all();
+            if (comm_)
+                for (int l = 0; l < nl_; ++l) {
+                    use(l);
+                    RJ_HIP(hipStreamSynchronize(comm_->xfer_stream(l)));
+                }
+            auto now = std::chrono::steady_clock::now();
+            fprintf(stderr, "[rj sharded] rank %d: %-28s %8.2f ms\n", rank_base_, what,
+                    std::chrono::duration<double, std::milli>(now - t_start).count());
+            t_start = now;
+        };
+        // ---- what every rank decides locally, then agrees on globally
+        std::vector<std::vector<uint64_t>> mine((size_t)nl_), all;
+        for (int l = 0; l < nl_; ++l) {
+            use(l);
+            ex_[l]->join_prepare(left[l], right[l], js, root_res != nullptr, st[l]);
+            bool ok = true;
+            for (Exec::Side* s : {&st[l].ls, &st[l].rs}) {
+                if (s->carry_mode == CARRY_ROWIDX) ok = false;  // a row index means nothing on another rank
+                if (s->carry_mode == CARRY_COLUMN && s->rel->cols[s->carry_col].kind == COL_IOTA) ok = false;
+            }
+            mine[l] = {left[l].n, right[l].n, ok ? 1ull : 0ull};
+        }
+        gather(mine, 3, all);
+        uint64_t tot_left = 0, tot_right = 0;
+        bool     ok = true;
+        for (int r = 0; r < world_; ++r) {
+            tot_left += all[r][0];
+            tot_right += all[r][1];
+            ok = ok && all[r][2] != 0;
+        }
+        auto all_empty = [&] {
+            std::vector<Rel> out((size_t)nl_);
+            for (int l = 0; l < nl_; ++l) {
+                use(l);
+                out[l] = ex_[l]->empty_rel(js, root_res ? (*root_res)[l] : nullptr);
+            }
+            return out;
+        };
+        // with an empty child the reference returns {} before looking at anything
+        // (src/execute.cpp:50); a probe key of another type matches nothing (:65-71)
+        if (tot_left == 0 || tot_right == 0 || st[0].type_mismatch) return all_empty();
+        if (!ok)
+            throw_fmt(RJ_ERR_UNSUPPORTED,
+                      "sharded join: a side needs more than one non-key column, a nullable or a VARCHAR "
+                      "column (its row index would travel, and means nothing on another rank)");
+        const int KW = st[0].KW;
+
+        // ---- stage A on every local rank, both sides
+        struct SideX {
+            Parted                A;       // partitioned by owner rank
+            std::vector<uint32_t> off;     // [world + 1] host copy of A.off
+            BufP                  recv[MAX_WORDS];
+            WordSrc               ws;      // what arrived
+            Ev                    ready, done;
+            Parted                P;       // stage B partitions
+        };
+        std::vector<SideX> bx((size_t)nl_), px((size_t)nl_);
+        const uint32_t     shiftA = rb_ ? 32 - rb_ : 31;
+        for (int l = 0; l < nl_; ++l) {
+            use(l);
+            Exec&    E = *ex_[l];
+            Context* c = g_->lane(l);
+            for (int side = 0; side < 2; ++side) {
+                Exec::Side& s = side == 0 ? st[l].bs() : st[l].ps();
+                SideX&      X = side == 0 ? bx[l] : px[l];
+                TupleSrc    src = E.make_src(st[l], s, js);
+                X.A = E.partition(&src, nullptr, KW, s.CW, rb_, shiftA, /*single pass*/ true);
+                X.off.assign((size_t)world_ + 1, 0);
+                RJ_HIP(hipMemcpyAsync(X.off.data(), X.A.off->p, ((size_t)world_ + 1) * 4,
+                                      hipMemcpyDeviceToHost, c->stream));
+                X.ready.make();
+                X.done.make();
+                RJ_HIP(hipEventRecord(X.ready.e, c->stream));
+            }
+        }
+        sync_all();  // the offsets are on the host now
+        lap("stage A (both sides)");
+
+        // ---- who sends how much to whom: cnt[src rank][side * world + dst rank]
+        for (int l = 0; l < nl_; ++l) {
+            mine[l].assign((size_t)2 * world_, 0);
+            for (int d = 0; d < world_; ++d) {
+                mine[l][d] = bx[l].off[d + 1] - bx[l].off[d];
+                mine[l][(size_t)world_ + d] = px[l].off[d + 1] - px[l].off[d];
+            }
+        }
+        gather(mine, (size_t)2 * world_, all);
+        lap("count all-gather");
+
+        // ---- the exchange: build side first, probe side queued behind it on the exchange streams
+        for (int side = 0; side < 2; ++side) {
+            std::vector<SideX>& XS = side == 0 ? bx : px;
+            // arrays of the partition layout (the same on every rank: KW, CW and the packing rule agree)
+            const int CW = side == 0 ? st[0].bs().CW : st[0].ps().CW;
+            int       n_arrays = 0;
+            for (int a = 0; a < MAX_WORDS; ++a)
+                if (array_width(XS[0].A, KW, CW, a)) n_arrays = a + 1;
+            std::vector<uint64_t> n_recv((size_t)nl_, 0);
+            for (int l = 0; l < nl_; ++l) {
+                use(l);
+                const int me = rank_base_ + l;
+                for (int s = 0; s < world_; ++s) n_recv[l] += all[s][(size_t)side * world_ + me];
+                if (n_recv[l] > 0xfffffff0ull) throw_fmt(RJ_ERR_UNSUPPORTED, "more than 2^32 tuples on one rank");
+                SideX& X = XS[l];
+                X.ws.n = n_recv[l];
+                X.ws.packed = X.A.packed;
+                for (int a = 0; a < n_arrays; ++a) {
+                    const uint32_t wbytes = array_width(X.A, KW, CW, a);
+                    if (!wbytes) continue;
+                    X.recv[a] = g_->lane(l)->buf(std::max<uint64_t>(n_recv[l], 1) * wbytes);
+                    X.ws.w.w[a] = X.recv[a]->as<uint32_t>();
+                }
+            }
+            for (int a = 0; a < n_arrays; ++a) {
+                const uint32_t wbytes = array_width(XS[0].A, KW, CW, a);
+                if (!wbytes) continue;
+                std::vector<XferSpec>   specs((size_t)nl_);
+                std::vector<hipEvent_t> ready, done;
+                for (int l = 0; l < nl_; ++l) {
+                    const int me = rank_base_ + l;
+                    XferSpec& sp = specs[l];
+                    SideX&    X = XS[l];
+                    sp.send = reinterpret_cast<const uint8_t*>(X.A.w.w[a]);
+                    sp.recv = reinterpret_cast<uint8_t*>(X.ws.w.w[a]);
+                    sp.send_off.assign((size_t)world_, 0);
+                    sp.send_cnt.assign((size_t)world_, 0);
+                    sp.recv_off.assign((size_t)world_, 0);
+                    sp.recv_cnt.assign((size_t)world_, 0);
+                    uint64_t roff = 0;
+                    for (int r = 0; r < world_; ++r) {
+                        sp.send_off[r] = (uint64_t)X.off[r] * wbytes;
+                        sp.send_cnt[r] = (uint64_t)(X.off[r + 1] - X.off[r]) * wbytes;
+                        const uint64_t c = all[r][(size_t)side * world_ + me];
+                        sp.recv_off[r] = roff * wbytes;
+                        sp.recv_cnt[r] = c * wbytes;
+                        roff += c;
+                    }
+                    ready.push_back(X.ready.e);
+                    done.push_back(X.done.e);
+                }
+                // (an exchange stream runs its all-to-alls in order: `done` of the last array
+                // covers the earlier ones)
+                if (comm_) {
+                    comm_->all_to_all(specs, ready, done);
+                } else {  // one rank, no transport: the slice is the whole
+                    use(0);
+                    RJ_HIP(hipMemcpyAsync(specs[0].recv, specs[0].send, specs[0].send_cnt[0],
+                                          hipMemcpyDeviceToDevice, g_->stream));
+                    RJ_HIP(hipEventRecord(done[0], g_->stream));
+                }
+            }
+        }
+
+        lap("exchange (both sides)");
+        // ---- stage B: each rank joins what it owns
+        std::vector<Rel> out((size_t)nl_);
+        std::vector<uint32_t> bits((size_t)nl_);
+        for (int l = 0; l < nl_; ++l) {
+            use(l);
+            Exec&    E = *ex_[l];
+            Context* c = g_->lane(l);
+            bits[l] = E.join_bits(js, std::max<uint64_t>(bx[l].ws.n, 1), rb_);
+            RJ_HIP(hipStreamWaitEvent(c->stream, bx[l].done.e, 0));
+            bx[l].P = E.partition(nullptr, &bx[l].ws, KW, st[l].bs().CW, bits[l]);
+        }
+        for (int l = 0; l < nl_; ++l) {
+            use(l);
+            Exec&    E = *ex_[l];
+            Context* c = g_->lane(l);
+            RJ_HIP(hipStreamWaitEvent(c->stream, px[l].done.e, 0));
+            px[l].P = E.partition(nullptr, &px[l].ws, KW, st[l].ps().CW, bits[l]);
+        }
+        for (int l = 0; l < nl_; ++l) {
+            use(l);
+            st[l].cap_hint = std::max(bx[l].ws.n, px[l].ws.n);
+            out[l] = ex_[l]->join_finish(st[l], js, &bx[l].P, &px[l].P, bits[l],
+                                         root_res ? (*root_res)[l] : nullptr);
+        }
+        lap("stage B (passes + join)");
+        // stage A's arrays were read by the exchange streams (and by peers): they may go back
+        // to the block caches only now that every rank has waited for its incoming copies
+        sync_all();
+        if (comm_)
+            for (int l = 0; l < nl_; ++l) {
+                use(l);
+                RJ_HIP(hipStreamSynchronize(comm_->xfer_stream(l)));
+            }
+        return out;
+    }
+
+    void gather(const std::vector<std::vector<uint64_t>>& mine, size_t k,
+                std::vector<std::vector<uint64_t>>& all) {
+        if (comm_) {
+            comm_->allgather_u64(mine, k, all);
+        } else {
+            all.assign(1, mine[0]);
+        }
+    }
+};
+
+bool node_shardable(const rj_plan* plan, uint64_t idx, int depth, std::string* why) {
+    if (idx >= plan->n_nodes || depth > 4096) return false;
+    const rj_node& n = plan->nodes[idx];
+    if (n.kind == RJ_NODE_SCAN) {
+        for (uint64_t k = 0; k < n.n_out; ++k)
+            if (n.out_type[k] == RJ_VARCHAR) {
+                if (why) *why = "a scan outputs a VARCHAR column";
+                return false;
+            }
+        return true;
+    }
+    if (n.kind != RJ_NODE_JOIN) return false;
+    if (!node_shardable(plan, n.left, depth + 1, why) || !node_shardable(plan, n.right, depth + 1, why))
+        return false;
+    if (n.left >= plan->n_nodes || n.right >= plan->n_nodes) return false;
+    const uint64_t lw = plan->nodes[n.left].n_out;
+    std::set<uint64_t> need_l, need_r;
+    for (uint64_t k = 0; k < n.n_out; ++k) {
+        const uint64_t c = n.out_idx[k];
+        if (c < lw) {
+            if (c != n.left_attr) need_l.insert(c);
+        } else if (c - lw != n.right_attr) {
+            need_r.insert(c - lw);
+        }
+    }
+    if (need_l.size() > 1 || need_r.size() > 1) {
+        if (why) *why = "a join side needs more than one non-key column";
+        return false;
+    }
+    return true;
+}
 }  // namespace
 
 Result* execute_plan(Context* ctx, const rj_plan* plan, Table* const* tables, uint64_t n_tables,
@@ -828,6 +1260,17 @@ Result* join_tuples(Context* ctx, const rj_tuples* build, const rj_tuples* probe
                     uint32_t skip_rank_bits, int flags) {
     Exec e(ctx, nullptr, nullptr, 0, flags);
     return e.run_tuples(build, probe, skip_rank_bits);
+}
+
+void execute_sharded(Context* group, const rj_plan* plan, Table* const* tables, uint64_t n_inputs,
+                     int flags, Result** out) {
+    ShardedExec e(group, plan, tables, n_inputs, flags);
+    e.run(out);
+}
+
+bool plan_shardable(const rj_plan* plan, std::string* why) {
+    if (!plan || plan->root >= plan->n_nodes) return false;
+    return node_shardable(plan, plan->root, 0, why);
 }
 
 void shard_partition(Context* ctx, const Table* t, uint64_t key_col, uint64_t carry_col,

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/rj.h"
+#include "rj_comm.hpp"
 #include "rj_device.hpp"
 #include "rj_kernels.hpp"
 
@@ -196,6 +197,14 @@ struct Context {
         } : (bool (*)(void*, const char*, hipEvent_t*, hipEvent_t*)) nullptr;
         return L;
     }
+    // multi-GPU: a context created over several devices is lane 0 of a group and owns one
+    // further single-device context per additional device ("lanes", one rank each) plus the
+    // exchange transport; a lane points back at its group
+    std::vector<Context*>  peers;  // lanes 1..n-1 (owned)
+    std::unique_ptr<Comm>  comm;   // set on lane 0 when the job has more than one rank
+    Context*               group = nullptr;
+    int                    n_lanes() const { return 1 + (int)peers.size(); }
+    Context*               lane(int i) { return i == 0 ? this : peers[(size_t)i - 1]; }
     int   n_cu = 0;
     int   compute_units();  // CUs of the device (persistent-kernel grids)
     BufP  buf(size_t bytes) { return std::make_shared<Buf>(this, bytes ? bytes : 16); }
@@ -217,6 +226,12 @@ Result* execute_plan(Context* ctx, const rj_plan* plan, Table* const* tables, ui
                      int flags, TableFetch* fetch = nullptr);
 Result* join_tuples(Context* ctx, const rj_tuples* build, const rj_tuples* probe,
                     uint32_t skip_rank_bits, int flags);
+// Sharded execution over the lanes of `group` (collective across the job's processes):
+// tables[l * n_inputs + i] = lane l's shard of input i; out[l] = lane l's slice of the result.
+void    execute_sharded(Context* group, const rj_plan* plan, Table* const* tables, uint64_t n_inputs,
+                        int flags, Result** out);
+// Can every JoinNode of the plan run sharded (at most one fixed-width non-key column per side)?
+bool    plan_shardable(const rj_plan* plan, std::string* why);
 void    shard_partition(Context* ctx, const Table* t, uint64_t key_col, uint64_t carry_col,
                         uint32_t n_ranks, rj_tuples* out, uint64_t* counts);
 

@@ -303,6 +303,15 @@ template <int PAIR>
 struct DenseLoaderT {
     static constexpr int pair = PAIR;
     Words in;
+    // two-halves interface of the fine histogram (see SrcLoader): the words are hashed already
+    __device__ __forceinline__ uint32_t issue_keys(uint32_t base, uint32_t end, uint32_t (&lo)[PT_ITEMS],
+                                                   uint32_t (&)[PT_ITEMS]) const {
+        return key_tile(base, end, lo);
+    }
+    __device__ __forceinline__ uint32_t finish_keys(uint32_t, uint32_t, uint32_t ok, uint32_t (&)[PT_ITEMS],
+                                                    uint32_t (&)[PT_ITEMS]) const {
+        return ok;
+    }
     __device__ __forceinline__ uint32_t key_tile(uint32_t base, uint32_t end,
                                                  uint32_t (&hk)[PT_ITEMS]) const {
         if (base + PT_TILE <= end) {  // full tile: four consecutive tuples per 16-byte load
@@ -384,6 +393,14 @@ using DenseLoader = DenseLoaderT<-1>;
 struct PackedLoader {
     static constexpr bool kPrefetch = true;  // load_tile has no post-processing: safe to issue early
     const uint2* in;
+    __device__ __forceinline__ uint32_t issue_keys(uint32_t base, uint32_t end, uint32_t (&lo)[PT_ITEMS],
+                                                   uint32_t (&)[PT_ITEMS]) const {
+        return key_tile(base, end, lo);
+    }
+    __device__ __forceinline__ uint32_t finish_keys(uint32_t, uint32_t, uint32_t ok, uint32_t (&)[PT_ITEMS],
+                                                    uint32_t (&)[PT_ITEMS]) const {
+        return ok;
+    }
     // keys only (histogram of a later pass): every second word of the pairs
     __device__ __forceinline__ uint32_t key_tile(uint32_t base, uint32_t end,
                                                  uint32_t (&hk)[PT_ITEMS]) const {
@@ -1889,6 +1906,18 @@ void launch_fine_hist_src(const Launch& L, const TupleSrc& src, int key_words, u
         SrcLoader<2, 0> ld{src};
         RJ_KLAUNCH(L, "pass1_hist", (k_fine_hist<SrcLoader<2, 0>>), grid, PT_THREADS, ld, src.n_rows,
                    shift, b1, b2, fine);
+    }
+}
+
+void launch_fine_hist_words(const Launch& L, const Words& in, bool packed, uint32_t n, uint32_t shift,
+                            uint32_t b1, uint32_t b2, uint32_t grid, uint32_t* fine) {
+    if (!grid || !n) return;
+    if (packed) {
+        PackedLoader ld{reinterpret_cast<const uint2*>(in.w[0])};
+        RJ_KLAUNCH(L, "pass1_hist", (k_fine_hist<PackedLoader>), grid, PT_THREADS, ld, n, shift, b1, b2, fine);
+    } else {
+        DenseLoader ld{in};
+        RJ_KLAUNCH(L, "pass1_hist", (k_fine_hist<DenseLoader>), grid, PT_THREADS, ld, n, shift, b1, b2, fine);
     }
 }
 

@@ -54,6 +54,10 @@ void launch_pass_hist_src(const Launch& L, const TupleSrc& src, int key_words, c
 // pass-2 offsets/cursors (off2[F1*F2 + 1], cursor2) and the pass-1 ones (off1[F1 + 1], cursor1).
 void launch_fine_hist_src(const Launch& L, const TupleSrc& src, int key_words, uint32_t shift,
                           uint32_t b1, uint32_t b2, uint32_t grid, uint32_t* fine);
+// the same over tuples that already sit in the partition layout (hashed words / packed pairs):
+// the passes behind a sharded join's exchange
+void launch_fine_hist_words(const Launch& L, const Words& in, bool packed, uint32_t n, uint32_t shift,
+                            uint32_t b1, uint32_t b2, uint32_t grid, uint32_t* fine);
 void launch_scan_fine(const Launch& L, const uint32_t* fine, uint32_t F1, uint32_t F2,
                       uint32_t* off2, uint32_t* cursor2, uint32_t* off1, uint32_t* cursor1);
 void launch_pass_scatter_src(const Launch& L, const TupleSrc& src, int key_words, int carry_words,

@@ -21,15 +21,27 @@ LIB_PATH = os.path.join(PKG_DIR, "librj.so")
 RJ_EXEC_KEEP_ON_DEVICE = 1
 
 
+class rj_comm_id(C.Structure):
+    _fields_ = [("bytes", C.c_char * 128)]
+
+
 class rj_config(C.Structure):
     _fields_ = [
         ("device", C.c_int32),
         ("profile", C.c_int32),
         ("stream", C.c_void_p),
         ("radix_bits", C.c_int32),
+        ("n_devices", C.c_int32),
+        ("devices", C.POINTER(C.c_int32)),
+        ("world_size", C.c_int32),
+        ("rank_base", C.c_int32),
+        ("comm_id", C.POINTER(rj_comm_id)),
+        ("exchange", C.c_int32),
         ("reserved0", C.c_int32),
-        ("reserved1", C.c_uint64),
     ]
+
+
+EXCHANGE_AUTO, EXCHANGE_P2P, EXCHANGE_RCCL = 0, 1, 2
 
 
 class rj_tuples(C.Structure):
@@ -63,6 +75,10 @@ EXPORTS = [
     "rj_context_create",
     "rj_context_destroy",
     "rj_last_error",
+    "rj_context_n_devices",
+    "rj_context_device",
+    "rj_comm_id_create",
+    "rj_execute_sharded",
     "rj_table_upload",
     "rj_table_adopt_device",
     "rj_table_release",
@@ -114,6 +130,23 @@ def _preload_torch_hip_runtime():
         C.CDLL(path, mode=C.RTLD_GLOBAL)
 
 
+def preload_torch_rccl():
+    """librj dlopens RCCL by soname on first use.  In a process that runs on PyTorch's bundled
+    HIP runtime (see above) the RCCL that goes with it is PyTorch's own copy: load that one
+    first, so the soname lookup binds to it and not to /opt/rocm's build for another runtime."""
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "librccl.so")
+    if os.path.exists(path):
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def load():
     """Load librj.so (built in-tree by ``__graft_entry__.build()`` / csrc/Makefile)."""
     global _LIB
@@ -135,6 +168,14 @@ def load():
     L.rj_context_destroy.restype = None
     L.rj_last_error.argtypes = [vp]
     L.rj_last_error.restype = C.c_char_p
+    L.rj_context_n_devices.argtypes = [vp]
+    L.rj_context_n_devices.restype = C.c_uint32
+    L.rj_context_device.argtypes = [vp, C.c_uint32]
+    L.rj_context_device.restype = vp
+    L.rj_comm_id_create.argtypes = [C.POINTER(rj_comm_id)]
+    L.rj_comm_id_create.restype = C.c_int
+    L.rj_execute_sharded.argtypes = [vp, C.POINTER(pl.rj_plan), C.POINTER(vp), u64, i32, C.POINTER(vp)]
+    L.rj_execute_sharded.restype = C.c_int
     L.rj_table_upload.argtypes = [vp, C.POINTER(pl.rj_input), C.POINTER(vp)]
     L.rj_table_upload.restype = C.c_int
     L.rj_table_adopt_device.argtypes = [vp, u64, u64, C.POINTER(i32), C.POINTER(vp), C.POINTER(u64), C.POINTER(vp)]
@@ -213,9 +254,11 @@ class Result:
         return t
 
     def free(self):
-        if self.h:
+        # a result / table holds blocks of its context's HBM cache: once the context is gone
+        # (destroy() before the object's finaliser ran) there is nothing left to give back
+        if self.h and getattr(self.ctx, "h", None):
             self.ctx.L.rj_result_free(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:
@@ -231,9 +274,9 @@ class Table:
         self.ctx, self.h, self.keep = ctx, handle, keep
 
     def release(self):
-        if self.h:
+        if self.h and getattr(self.ctx, "h", None):
             self.ctx.L.rj_table_release(self.ctx.h, self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:
@@ -245,21 +288,74 @@ class Table:
 class Context:
     """rj_context*: ``Contest::build_context()`` / ``destroy_context()``."""
 
-    def __init__(self, device=-1, profile=False, stream=None, radix_bits=0):
+    def __init__(self, device=-1, profile=False, stream=None, radix_bits=0, devices=None, world_size=0,
+                 rank_base=0, comm_id=None, exchange=EXCHANGE_AUTO, _lane_of=None, _handle=None):
+        """devices: HIP ordinals this context owns (one rank each; an ordinal may repeat =
+        virtual ranks on one GPU); world_size/rank_base/comm_id: this process' place in a
+        multi-process job (comm_id = bytes from ``make_comm_id()`` of one process)."""
         self.L = load()
-        cfg = rj_config(device, 1 if profile else 0, stream, radix_bits, 0, 0)
+        self._lanes = None
+        if _lane_of is not None:  # a device of a group context: borrowed handle
+            self.h, self.group = C.c_void_p(_handle), _lane_of
+            return
+        self.group = None
+        cfg = rj_config()
+        cfg.device, cfg.profile, cfg.stream, cfg.radix_bits = device, 1 if profile else 0, stream, radix_bits
+        if devices is not None:
+            self._devs = (C.c_int32 * len(devices))(*devices)
+            cfg.n_devices, cfg.devices = len(devices), self._devs
+        cfg.world_size, cfg.rank_base, cfg.exchange = world_size, rank_base, exchange
+        if comm_id is not None or exchange == EXCHANGE_RCCL:
+            preload_torch_rccl()
+        if comm_id is not None:
+            self._cid = rj_comm_id()
+            if len(comm_id) != 128:
+                raise ValueError("comm_id must be the 128 bytes of make_comm_id()")
+            C.memmove(C.addressof(self._cid), bytes(comm_id), 128)  # (.bytes would be a copy)
+            cfg.comm_id = C.pointer(self._cid)
         h = C.c_void_p()
         rc = self.L.rj_context_create(C.byref(h), C.byref(cfg))
         if rc != 0:
             raise RjError(rc, (self.L.rj_last_error(None) or b"").decode())
         self.h = h
 
+    @property
+    def n_devices(self):
+        return int(self.L.rj_context_n_devices(self.h))
+
+    def lane(self, i) -> "Context":
+        """The single-device context of local device i (tables are uploaded / adopted per
+        device); owned by this context."""
+        if self._lanes is None:
+            self._lanes = [Context(_lane_of=self, _handle=self.L.rj_context_device(self.h, k)) for k in range(self.n_devices)]
+        return self._lanes[i]
+
+    def execute_sharded(self, plan: pl.Plan, tables_per_device):
+        """rj_execute_sharded: tables_per_device[d][i] = shard of input i on local device d.
+        -> one Result per local device (its slice of the join result)."""
+        cached = getattr(plan, "_c_resident", None)
+        if cached is None:
+            cached = pl.plan_to_c(plan, with_inputs=False)
+            plan._c_resident = cached
+        cplan, keep = cached
+        nd = self.n_devices
+        n_in = len(tables_per_device[0])
+        flat = [t.h for d in range(nd) for t in tables_per_device[d]]
+        hs = (C.c_void_p * max(1, len(flat)))(*flat)
+        outs = (C.c_void_p * nd)()
+        self._check(self.L.rj_execute_sharded(self.h, C.byref(cplan), hs, n_in, RJ_EXEC_KEEP_ON_DEVICE, outs))
+        return [Result(self.lane(d), C.c_void_p(outs[d])) for d in range(nd)]
+
     def _check(self, rc):
         if rc != 0:
             raise RjError(rc, (self.L.rj_last_error(self.h) or b"").decode())
 
     def destroy(self):
+        if getattr(self, "group", None) is not None:
+            return  # a device of a group: the group owns it
         if getattr(self, "h", None):
+            for ln in self._lanes or []:
+                ln.h = None
             self.L.rj_context_destroy(self.h)
             self.h = None
 
@@ -347,6 +443,17 @@ class Context:
             "hbm_bytes": int(d.hbm_bytes),
             "lds_per_cu": int(d.lds_per_cu),
         }
+
+
+def make_comm_id() -> bytes:
+    """rj_comm_id_create: 128 bytes to hand to every rank of a multi-process job."""
+    L = load()
+    preload_torch_rccl()
+    cid = rj_comm_id()
+    rc = L.rj_comm_id_create(C.byref(cid))
+    if rc != 0:
+        raise RjError(rc, (L.rj_last_error(None) or b"").decode())
+    return C.string_at(C.addressof(cid), 128)  # (c_char arrays stop at the first NUL when read as bytes)
 
 
 # ---------------------------------------------------------------- reference API --

@@ -149,15 +149,19 @@ class Relations:
         return pl.INT64 if self.payload64 else pl.INT32
 
 
-def make_relations(name, device, rows=None, rank=0, world=1) -> Relations:
+def make_relations(name, device, rows=None, rank=0, world=1, sharded=None) -> Relations:
     """rows = rows per relation OVERALL (default: the workload's own size); a rank of a
-    `world`-way run holds the contiguous row range [rank, rank+1) * rows / world of both."""
+    `world`-way run holds the contiguous row range [rank, rank+1) * rows / world of both.
+    sharded (default: world > 1): build keys are the closed-form bijection of the global row
+    index (checkable on any rank) instead of a random permutation."""
     w = WORKLOADS[name]
     total = int(rows or w["rows"])
     lo, hi = total * rank // world, total * (rank + 1) // world
     n = hi - lo
     g = torch.Generator(device=device)
-    if world == 1:
+    if sharded is None:
+        sharded = world > 1
+    if not sharded:
         g.manual_seed(1)
         rk = torch.randperm(total, generator=g, device=device, dtype=torch.int64).to(torch.int32)
     else:

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(lib):
     for name in _declared():
         assert hasattr(lib, name), f"librj.so does not export {name}"
     lib.rj_abi_version.restype = ctypes.c_int
-    assert lib.rj_abi_version() == 1
+    assert lib.rj_abi_version() == 2
 
 
 def test_no_gpu_fails_loudly_without_fallback(lib):

@@ -1,0 +1,219 @@
+"""The multi-GPU join behind the C-ABI (rj_execute_sharded / a context that owns several
+devices), exercised on ONE GPU: a context over devices [0, 0, ...] runs N virtual ranks with the
+real stage A / exchange / stage B code (the peer-copy transport degenerates to device-to-device
+copies), and the RCCL transport is run at world size 1 (self send/recv).  Results of all ranks
+together must equal the oracle's join of the unsharded inputs (multiset digest).  Real multi-GPU
+runs are the driver's (bench.py --gpus N)."""
+import numpy as np
+import pytest
+
+import _oracle
+from pyrj import capi
+from pyrj import pages as pg
+from pyrj import plan as pl
+
+pytestmark = pytest.mark.gpu
+
+
+def shard_table(t: pl.ColumnarTable, n_ranks: int):
+    """Contiguous row shards of a fixed-width table (decode + re-encode on the host)."""
+    cols = [pg.unpack_fixed(c.pages, t.num_rows, c.type) for c in t.columns]
+    cuts = [t.num_rows * r // n_ranks for r in range(n_ranks + 1)]
+    out = []
+    for r in range(n_ranks):
+        a, b = cuts[r], cuts[r + 1]
+        out.append(pl.make_table([(c.type, v[a:b], m[a:b]) for c, (v, m) in zip(t.columns, cols)]))
+    return out
+
+
+def combine(digests):
+    n = sum(d[0] for d in digests)
+    s = sum(d[1] for d in digests) & 0xFFFFFFFFFFFFFFFF
+    x = 0
+    for d in digests:
+        x ^= d[2]
+    return (n, s, x)
+
+
+def run_sharded(plan, n_ranks, **ctx_kw):
+    ctx = capi.Context(devices=[0] * n_ranks, **ctx_kw)
+    tables = []
+    try:
+        assert ctx.n_devices == n_ranks
+        shards = [shard_table(t, n_ranks) for t in plan.inputs]
+        tables = [[ctx.lane(d).upload(shards[i][d]) for i in range(len(plan.inputs))] for d in range(n_ranks)]
+        res = ctx.execute_sharded(plan, tables)
+        out = [r.to_table() for r in res]
+        for r in res:
+            r.free()
+        return out
+    finally:
+        for row in tables:
+            for t in row:
+                t.release()
+        ctx.destroy()
+
+
+def check_against_oracle(plan, n_ranks, **ctx_kw):
+    parts = run_sharded(plan, n_ranks, **ctx_kw)
+    want = _oracle.execute(plan)
+    assert sum(p.num_rows for p in parts) == want.num_rows
+    for p in parts:
+        assert [c.type for c in p.columns] == [c.type for c in want.columns]
+    assert combine([pl.table_digest(p) for p in parts if p.num_rows]) == pl.table_digest(want)
+    return parts
+
+
+def join_plan(bt, pt, btypes, ptypes, outs, build_left=True):
+    p = pl.Plan()
+    if build_left:
+        p.new_scan_node(0, list(enumerate(btypes)))
+        p.new_scan_node(1, list(enumerate(ptypes)))
+        p.new_join_node(True, 0, 1, 0, 0, outs)
+        p.new_input(bt)
+        p.new_input(pt)
+    else:
+        p.new_scan_node(0, list(enumerate(ptypes)))
+        p.new_scan_node(1, list(enumerate(btypes)))
+        p.new_join_node(False, 0, 1, 0, 0, outs)
+        p.new_input(pt)
+        p.new_input(bt)
+    p.root = 2
+    return p
+
+
+@pytest.mark.parametrize("n_ranks", [2, 4, 8])
+def test_baseline_shape_int32_payloads(n_ranks):
+    """config-2/4 shape: unique build keys, uniform probe keys, INT32 payloads (packed pairs:
+    ONE array moves per relation)"""
+    rng = np.random.default_rng(10 + n_ranks)
+    nb, npr = 1_500_000, 2_500_000
+    bt = pl.make_table([(pl.INT32, rng.permutation(nb).astype(np.int32)), (pl.INT32, np.arange(nb, dtype=np.int32))])
+    pt = pl.make_table([(pl.INT32, rng.integers(0, nb + 100_000, npr).astype(np.int32)), (pl.INT32, np.arange(npr, dtype=np.int32))])
+    parts = check_against_oracle(join_plan(bt, pt, [pl.INT32, pl.INT32], [pl.INT32, pl.INT32], [(0, pl.INT32), (1, pl.INT32), (3, pl.INT32)]), n_ranks)
+    # every rank owns a share of the result (hash sharding balances uniform keys)
+    assert all(p.num_rows > 0.5 * sum(q.num_rows for q in parts) / n_ranks for p in parts)
+
+
+@pytest.mark.parametrize("build_left", [True, False])
+def test_int64_payloads_null_keys_duplicates(build_left):
+    """config-3 shape at small scale: INT64 payloads on both sides (12-byte tuples: a key array
+    and a pair array move per relation), NULL keys on both sides, duplicate build keys, a hot
+    probe key"""
+    rng = np.random.default_rng(21)
+    nb, npr = 400_000, 900_000
+    bk = rng.integers(0, 300_000, nb).astype(np.int32)
+    pk = rng.integers(0, 330_000, npr).astype(np.int32)
+    pk[rng.random(npr) < 0.05] = 4242
+    bt = pl.make_table([(pl.INT32, bk, rng.random(nb) > 0.03), (pl.INT64, rng.integers(-(2**62), 2**62, nb).astype(np.int64))])
+    pt = pl.make_table([(pl.INT32, pk, rng.random(npr) > 0.02), (pl.INT64, rng.integers(-(2**62), 2**62, npr).astype(np.int64))])
+    if build_left:
+        outs = [(0, pl.INT32), (1, pl.INT64), (3, pl.INT64)]
+    else:
+        outs = [(3, pl.INT64), (0, pl.INT32), (1, pl.INT64)]
+    check_against_oracle(join_plan(bt, pt, [pl.INT32, pl.INT64], [pl.INT32, pl.INT64], outs, build_left), 4)
+
+
+def test_int64_keys_and_key_only_outputs():
+    """KW = 2 (INT64 keys), one side without payload, the other with an INT32 payload"""
+    rng = np.random.default_rng(22)
+    nb, npr = 200_000, 500_000
+    bk = (rng.integers(0, 150_000, nb).astype(np.int64) * 4_000_000_007) - 99
+    pk = rng.choice(bk, npr)
+    bt = pl.make_table([(pl.INT64, bk)])
+    pt = pl.make_table([(pl.INT64, pk), (pl.INT32, np.arange(npr, dtype=np.int32))])
+    p = pl.Plan()
+    p.new_scan_node(0, [(0, pl.INT64)])
+    p.new_scan_node(1, [(0, pl.INT64), (1, pl.INT32)])
+    p.new_join_node(True, 0, 1, 0, 0, [(1, pl.INT64), (2, pl.INT32)])
+    p.new_input(bt)
+    p.new_input(pt)
+    p.root = 2
+    check_against_oracle(p, 2)
+
+
+def test_forced_radix_bits_reach_into_the_rank_bits():
+    """rj_config.radix_bits = 21 with 8 ranks: 21 radix bits + 3 rank bits leave 8 varying bits
+    above the radix digits.  The rank bits are constant on a rank; bucket indices come from the
+    LOW bits above the radix digits — exactly the ones that still vary — so every distinct key of a
+    partition keeps its own home bucket.  Results must not depend on any of it."""
+    rng = np.random.default_rng(23)
+    nb, npr = 300_000, 600_000
+    bt = pl.make_table([(pl.INT32, rng.integers(0, 250_000, nb).astype(np.int32)), (pl.INT32, np.arange(nb, dtype=np.int32))])
+    pt = pl.make_table([(pl.INT32, rng.integers(0, 260_000, npr).astype(np.int32)), (pl.INT32, np.arange(npr, dtype=np.int32))])
+    check_against_oracle(join_plan(bt, pt, [pl.INT32, pl.INT32], [pl.INT32, pl.INT32], [(0, pl.INT32), (1, pl.INT32), (3, pl.INT32)]), 8, radix_bits=21)
+
+
+def test_two_joins_stay_sharded():
+    """(R ⋈ S) ⋈ T: the intermediate result stays distributed and is re-sharded by the parent's key"""
+    rng = np.random.default_rng(24)
+    r = pl.make_table([(pl.INT32, rng.permutation(100_000).astype(np.int32)), (pl.INT32, rng.integers(0, 50_000, 100_000).astype(np.int32))])
+    s = pl.make_table([(pl.INT32, rng.integers(0, 100_000, 300_000).astype(np.int32))])
+    t = pl.make_table([(pl.INT32, rng.integers(0, 50_000, 80_000).astype(np.int32)), (pl.INT64, rng.integers(0, 2**40, 80_000).astype(np.int64))])
+    p = pl.Plan()
+    a = p.new_scan_node(0, [(0, pl.INT32), (1, pl.INT32)])
+    b = p.new_scan_node(1, [(0, pl.INT32)])
+    j1 = p.new_join_node(True, a, b, 0, 0, [(0, pl.INT32), (1, pl.INT32)])  # -> (r.key, r.fk)
+    c = p.new_scan_node(2, [(0, pl.INT32), (1, pl.INT64)])
+    j2 = p.new_join_node(False, j1, c, 1, 0, [(0, pl.INT32), (3, pl.INT64), (1, pl.INT32)])
+    for x in (r, s, t):
+        p.new_input(x)
+    p.root = j2
+    check_against_oracle(p, 4)
+
+
+def test_empty_sides_and_empty_shards():
+    rng = np.random.default_rng(25)
+    bt = pl.make_table([(pl.INT32, np.arange(5, dtype=np.int32)), (pl.INT32, np.arange(5, dtype=np.int32))])  # fewer rows than ranks
+    pt = pl.make_table([(pl.INT32, rng.integers(0, 7, 1000).astype(np.int32)), (pl.INT32, np.arange(1000, dtype=np.int32))])
+    check_against_oracle(join_plan(bt, pt, [pl.INT32, pl.INT32], [pl.INT32, pl.INT32], [(0, pl.INT32), (1, pl.INT32), (3, pl.INT32)]), 8)
+    empty = pl.make_table([(pl.INT32, np.zeros(0, np.int32)), (pl.INT32, np.zeros(0, np.int32))])
+    parts = check_against_oracle(join_plan(empty, pt, [pl.INT32, pl.INT32], [pl.INT32, pl.INT32], [(0, pl.INT32), (1, pl.INT32), (3, pl.INT32)]), 2)
+    assert all(p.num_rows == 0 and all(c.pages.shape[0] == 0 for c in p.columns) for p in parts)
+
+
+def test_unshardable_plans_are_refused_loudly():
+    rng = np.random.default_rng(26)
+    n = 10_000
+    bt = pl.make_table([(pl.INT32, rng.permutation(n).astype(np.int32)), (pl.INT32, np.arange(n, dtype=np.int32)), (pl.INT64, np.arange(n, dtype=np.int64))])
+    pt = pl.make_table([(pl.INT32, rng.integers(0, n, n).astype(np.int32)), (pl.INT32, np.arange(n, dtype=np.int32))])
+    p = pl.Plan()
+    p.new_scan_node(0, [(0, pl.INT32), (1, pl.INT32), (2, pl.INT64)])
+    p.new_scan_node(1, [(0, pl.INT32), (1, pl.INT32)])
+    p.new_join_node(True, 0, 1, 0, 0, [(0, pl.INT32), (1, pl.INT32), (2, pl.INT64), (4, pl.INT32)])  # two payload columns of one side
+    p.new_input(bt)
+    p.new_input(pt)
+    p.root = 2
+    with pytest.raises(capi.RjError) as e:
+        run_sharded(p, 2)
+    assert e.value.code == 5 and "row index" in e.value.message
+
+
+def test_rccl_transport_at_world_size_one():
+    """The RCCL code path (communicator from an rj_comm_id, count all-gather, grouped
+    ncclSend/ncclRecv to self) on the one GPU this box has"""
+    rng = np.random.default_rng(27)
+    nb, npr = 300_000, 700_000
+    bt = pl.make_table([(pl.INT32, rng.permutation(nb).astype(np.int32)), (pl.INT64, rng.integers(0, 2**50, nb).astype(np.int64))])
+    pt = pl.make_table([(pl.INT32, rng.integers(0, nb, npr).astype(np.int32)), (pl.INT32, np.arange(npr, dtype=np.int32))])
+    cid = capi.make_comm_id()
+    assert len(cid) == 128
+    check_against_oracle(join_plan(bt, pt, [pl.INT32, pl.INT64], [pl.INT32, pl.INT32], [(0, pl.INT32), (1, pl.INT64), (3, pl.INT32)]), 1,
+                         world_size=1, rank_base=0, comm_id=cid, exchange=capi.EXCHANGE_RCCL)
+
+
+def test_plain_context_runs_execute_sharded_as_one_rank():
+    rng = np.random.default_rng(28)
+    n = 200_000
+    bt = pl.make_table([(pl.INT32, rng.permutation(n).astype(np.int32)), (pl.INT32, np.arange(n, dtype=np.int32))])
+    pt = pl.make_table([(pl.INT32, rng.integers(0, n, 2 * n).astype(np.int32)), (pl.INT32, np.arange(2 * n, dtype=np.int32))])
+    plan = join_plan(bt, pt, [pl.INT32, pl.INT32], [pl.INT32, pl.INT32], [(0, pl.INT32), (1, pl.INT32), (3, pl.INT32)])
+    ctx = capi.Context()
+    try:
+        tables = [[ctx.lane(0).upload(t) for t in plan.inputs]]
+        (res,) = ctx.execute_sharded(plan, tables)
+        got = res.to_table()
+        res.free()
+        assert pl.table_digest(got) == pl.table_digest(_oracle.execute(plan))
+    finally:
+        ctx.destroy()
