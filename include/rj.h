@@ -250,6 +250,8 @@ typedef struct rj_device_info {
     int32_t  wavefront;
     uint64_t hbm_bytes;
     uint64_t lds_per_cu;
+    int32_t  device_count;  /* HIP devices visible to this process */
+    int32_t  reserved;
 } rj_device_info;
 int rj_device_query(rj_context* ctx, rj_device_info* out);
 

@@ -203,6 +203,13 @@ int rj_execute(rj_context* ctx, const rj_plan* plan, rj_result** out) {
                 col_used[nd.base_table_id][nd.out_idx[k]] = true;
             }
         }
+        // a context that owns several devices shards the plan across them when it can
+        if (ctx->n_lanes() > 1 && !ctx->group) {
+            if (Result* r = execute_host_sharded(ctx, plan, used, col_used)) {
+                *out = static_cast<rj_result*>(r);
+                return;
+            }
+        }
         const bool  diag = ctx->tune.diag >= 2;
         auto        t0 = std::chrono::steady_clock::now();
         const uint64_t m0 = ctx->pool.n_malloc, tr0 = ctx->pool.n_trim;
@@ -338,6 +345,9 @@ int rj_device_query(rj_context* ctx, rj_device_info* out) {
         out->wavefront = p.warpSize;
         out->hbm_bytes = p.totalGlobalMem;
         out->lds_per_cu = p.maxSharedMemoryPerMultiProcessor;
+        int n = 0;
+        RJ_HIP(hipGetDeviceCount(&n));
+        out->device_count = n;
     });
 }
 

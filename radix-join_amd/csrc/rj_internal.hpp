@@ -143,9 +143,18 @@ struct Table {
 // ------------------------------------------------------------------ results --
 struct ResultColumn {
     int32_t              type = 0;
-    uint64_t             n_pages = 0;
+    uint64_t             n_pages = 0;   // all pages of the column (dev_pages + more)
     BufP                 dev_pages;   // fixed-width
     std::vector<uint8_t> host_pages;  // VARCHAR (encoded on the host)
+    // a result gathered from several devices (rj_execute on a multi-device context): the pages
+    // of the other ranks, in rank order behind dev_pages (which then holds n_first pages)
+    struct Part {
+        Context* ctx;
+        BufP     pages;
+        uint64_t n_pages;
+    };
+    std::vector<Part> more;
+    uint64_t          n_first = 0;  // pages in dev_pages when `more` is in use
 };
 
 struct Result {
@@ -260,6 +269,11 @@ class AsyncUpload : public TableFetch {
 Table* table_adopt(Context* ctx, uint64_t num_rows, uint64_t n_cols, const int32_t* types,
                    const void* const* dev_pages, const uint64_t* n_pages);
 void   result_copy_pages(Result* r, uint64_t col, void* const* dst, uint64_t n_dst);
+// rj_execute on a context that owns several devices: shard the host inputs by row ranges, run
+// the plan sharded and gather the ranks' pages into one result.  nullptr = this plan / these
+// inputs cannot be sharded (the caller runs them on the first device).
+Result* execute_host_sharded(Context* group, const rj_plan* plan, const std::vector<bool>& used,
+                             const std::vector<std::vector<bool>>& col_used);
 
 // rj_hostpool.cpp (host only)
 // fn(b, e) over disjoint ranges of at most `grain` items covering [0, n), on the process-wide

@@ -364,33 +364,20 @@ AsyncUpload::~AsyncUpload() {
     if (im.start) (void)hipEventDestroy(im.start);
 }
 
-// Result pages -> caller-owned 8 KiB blocks (e.g. `new Page`, so the harness's
-// Column::~Column, reference include/plan.h:95-99, can delete them).
-void result_copy_pages(Result* r, uint64_t col, void* const* dst, uint64_t n_dst) {
-    if (col >= r->cols.size()) throw_fmt(RJ_ERR_ARG, "column out of range");
-    ResultColumn& c = r->cols[col];
-    if (n_dst < c.n_pages) throw_fmt(RJ_ERR_ARG, "destination has too few pages");
-    if (c.n_pages == 0) return;
-    if (c.type == RJ_VARCHAR || !c.dev_pages) {
-        const uint8_t* src = c.host_pages.data();
-        parallel_for(c.n_pages, 256, [&](size_t b, size_t e) {
-            for (size_t p = b; p < e; ++p) memcpy(dst[p], src + p * PAGE_BYTES, PAGE_BYTES);
-        });
-        return;
-    }
-    Context* ctx = r->ctx;
-    uint8_t* stage = static_cast<uint8_t*>(ctx->staging(2 * CHUNK_PAGES * PAGE_BYTES));
-    // D2H of chunk k+1 overlaps the host scatter of chunk k
-    uint64_t   n_chunks = (c.n_pages + CHUNK_PAGES - 1) / CHUNK_PAGES;
+// D2H of `n_pages` contiguous page images on `ctx`'s device into caller-owned 8 KiB blocks;
+// the copy of chunk k+1 overlaps the host scatter of chunk k
+static void copy_part_pages(Context* ctx, const uint8_t* dev, uint64_t n_pages, void* const* dst) {
+    RJ_HIP(hipSetDevice(ctx->device));
+    uint8_t*   stage = static_cast<uint8_t*>(ctx->staging(2 * CHUNK_PAGES * PAGE_BYTES));
+    uint64_t   n_chunks = (n_pages + CHUNK_PAGES - 1) / CHUNK_PAGES;
     hipEvent_t ev[2];
     RJ_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
     RJ_HIP(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
     auto issue = [&](uint64_t k) {
-        uint64_t p0 = k * CHUNK_PAGES, np = std::min<uint64_t>(CHUNK_PAGES, c.n_pages - p0);
+        uint64_t p0 = k * CHUNK_PAGES, np = std::min<uint64_t>(CHUNK_PAGES, n_pages - p0);
         int      h = (int)(k & 1);
-        RJ_HIP(hipMemcpyAsync(stage + (size_t)h * CHUNK_PAGES * PAGE_BYTES,
-                              c.dev_pages->as<uint8_t>() + p0 * PAGE_BYTES, np * PAGE_BYTES,
-                              hipMemcpyDeviceToHost, ctx->stream));
+        RJ_HIP(hipMemcpyAsync(stage + (size_t)h * CHUNK_PAGES * PAGE_BYTES, dev + p0 * PAGE_BYTES,
+                              np * PAGE_BYTES, hipMemcpyDeviceToHost, ctx->stream));
         RJ_HIP(hipEventRecord(ev[h], ctx->stream));
     };
     try {
@@ -399,7 +386,7 @@ void result_copy_pages(Result* r, uint64_t col, void* const* dst, uint64_t n_dst
             int h = (int)(k & 1);
             RJ_HIP(hipEventSynchronize(ev[h]));
             if (k + 1 < n_chunks) issue(k + 1);
-            uint64_t       p0 = k * CHUNK_PAGES, np = std::min<uint64_t>(CHUNK_PAGES, c.n_pages - p0);
+            uint64_t       p0 = k * CHUNK_PAGES, np = std::min<uint64_t>(CHUNK_PAGES, n_pages - p0);
             const uint8_t* s = stage + (size_t)h * CHUNK_PAGES * PAGE_BYTES;
             void* const*   d = dst + p0;
             parallel_for(np, 256, [&](size_t b, size_t e) {
@@ -415,6 +402,123 @@ void result_copy_pages(Result* r, uint64_t col, void* const* dst, uint64_t n_dst
     }
     (void)hipEventDestroy(ev[0]);
     (void)hipEventDestroy(ev[1]);
+}
+
+// Result pages -> caller-owned 8 KiB blocks (e.g. `new Page`, so the harness's
+// Column::~Column, reference include/plan.h:95-99, can delete them).
+void result_copy_pages(Result* r, uint64_t col, void* const* dst, uint64_t n_dst) {
+    if (col >= r->cols.size()) throw_fmt(RJ_ERR_ARG, "column out of range");
+    ResultColumn& c = r->cols[col];
+    if (n_dst < c.n_pages) throw_fmt(RJ_ERR_ARG, "destination has too few pages");
+    if (c.n_pages == 0) return;
+    if (c.type == RJ_VARCHAR || (!c.dev_pages && c.more.empty())) {
+        const uint8_t* src = c.host_pages.data();
+        parallel_for(c.n_pages, 256, [&](size_t b, size_t e) {
+            for (size_t p = b; p < e; ++p) memcpy(dst[p], src + p * PAGE_BYTES, PAGE_BYTES);
+        });
+        return;
+    }
+    // the column's pages may sit on several devices (a result gathered from a sharded run)
+    std::vector<ResultColumn::Part> parts;
+    parts.push_back({r->ctx, c.dev_pages, c.more.empty() ? c.n_pages : c.n_first});
+    for (const ResultColumn::Part& p : c.more) parts.push_back(p);
+    uint64_t done = 0;
+    for (const ResultColumn::Part& part : parts) {
+        if (part.n_pages == 0) continue;
+        copy_part_pages(part.ctx, part.pages->as<uint8_t>(), part.n_pages, dst + done);
+        done += part.n_pages;
+    }
+    RJ_HIP(hipSetDevice(r->ctx->device));
+}
+
+// ------------------------------------------------------ rj_execute over several devices
+namespace {
+
+// all pages but the last full, every validity bit set, rows add up: addressable in place
+bool host_column_regular(const rj_column& hc, uint64_t num_rows) {
+    if (hc.type != RJ_INT32 && hc.type != RJ_INT64 && hc.type != RJ_FP64) return false;
+    if (hc.n_pages == 0) return num_rows == 0;
+    const uint32_t        rows_full = hc.type == RJ_INT32 ? ROWS32 : ROWS64;
+    std::atomic<uint64_t> bad{0}, total{0};
+    parallel_for(hc.n_pages, 1024, [&](size_t b, size_t e) {
+        uint64_t nb = 0, tot = 0;
+        for (size_t p = b; p < e; ++p) {
+            const uint8_t* pg = static_cast<const uint8_t*>(hc.pages[p]);
+            uint16_t       nr;
+            memcpy(&nr, pg, 2);
+            tot += nr;
+            nb += !bitmap_all_ones(pg, nr) || (p + 1 < hc.n_pages ? nr != rows_full : (nr > rows_full || nr == 0));
+        }
+        bad += nb;
+        total += tot;
+    });
+    return bad.load() == 0 && total.load() == num_rows;
+}
+
+}  // namespace
+
+Result* execute_host_sharded(Context* g, const rj_plan* plan, const std::vector<bool>& used,
+                             const std::vector<std::vector<bool>>& col_used) {
+    const int nl = g->n_lanes();
+    if (nl < 2 || !g->comm || g->comm->world() != nl) return nullptr;
+    if (!plan_shardable(plan, nullptr)) return nullptr;
+    for (uint64_t i = 0; i < plan->n_inputs; ++i) {
+        if (!used[i]) continue;
+        const rj_input& in = plan->inputs[i];
+        for (uint64_t c = 0; c < in.n_cols; ++c)
+            if (col_used[i][c] && !host_column_regular(in.cols[c], in.num_rows)) return nullptr;
+    }
+    // Row cuts at multiples of 1984 * 1007 rows: a page boundary of INT32 and of INT64/FP64
+    // columns alike (the two page capacities are coprime), so a shard is a sub-range of every
+    // column's page pointers.
+    constexpr uint64_t U = (uint64_t)ROWS32 * ROWS64;
+    std::vector<std::vector<std::unique_ptr<Table>>> tabs((size_t)nl);
+    std::vector<Table*>                              flat((size_t)nl * plan->n_inputs, nullptr);
+    std::vector<std::vector<rj_column>>              views;  // keep the column views alive
+    for (int l = 0; l < nl; ++l) {
+        Context* c = g->lane(l);
+        RJ_HIP(hipSetDevice(c->device));
+        for (uint64_t i = 0; i < plan->n_inputs; ++i) {
+            const rj_input& in = plan->inputs[i];
+            rj_input        view{};
+            if (used[i]) {
+                const uint64_t r0 = l == 0 ? 0 : (in.num_rows * (uint64_t)l / nl) / U * U;
+                const uint64_t r1 = l + 1 == nl ? in.num_rows : (in.num_rows * (uint64_t)(l + 1) / nl) / U * U;
+                views.emplace_back(in.cols, in.cols + in.n_cols);
+                std::vector<rj_column>& vc = views.back();
+                for (uint64_t k = 0; k < in.n_cols; ++k) {
+                    if (!col_used[i][k]) continue;
+                    const uint64_t rf = vc[k].type == RJ_INT32 ? ROWS32 : ROWS64;
+                    const uint64_t p0 = r0 / rf, p1 = (r1 + rf - 1) / rf;
+                    vc[k].pages = in.cols[k].pages + p0;
+                    vc[k].n_pages = p1 - p0;
+                }
+                view.num_rows = r1 - r0;
+                view.n_cols = in.n_cols;
+                view.cols = vc.data();
+            }
+            tabs[l].emplace_back(table_upload(c, &view, used[i] ? &col_used[i] : nullptr, true));
+            flat[(size_t)l * plan->n_inputs + i] = tabs[l].back().get();
+        }
+    }
+    std::vector<Result*> parts((size_t)nl, nullptr);
+    execute_sharded(g, plan, flat.data(), plan->n_inputs, 0, parts.data());
+    // gather: rank 0's result takes the others' pages behind its own (pages of a Column need
+    // not be full, reference src/build_table.cpp:326-343, so concatenation is a valid column)
+    std::unique_ptr<Result> res(parts[0]);
+    for (ResultColumn& rc : res->cols) rc.n_first = rc.n_pages;
+    for (int l = 1; l < nl; ++l) {
+        std::unique_ptr<Result> p(parts[l]);
+        res->num_rows += p->num_rows;
+        for (size_t k = 0; k < res->cols.size() && k < p->cols.size(); ++k) {
+            ResultColumn& rc = res->cols[k];
+            if (p->cols[k].n_pages == 0) continue;
+            rc.more.push_back({p->ctx, p->cols[k].dev_pages, p->cols[k].n_pages});
+            rc.n_pages += p->cols[k].n_pages;
+        }
+    }
+    RJ_HIP(hipSetDevice(g->device));
+    return res.release();
 }
 
 }  // namespace rj

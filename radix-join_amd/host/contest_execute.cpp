@@ -13,6 +13,7 @@
 // (src/execute.cpp:280, build_table.cpp:335).
 #include <plan.h>
 
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -28,10 +29,45 @@ namespace {
 }
 }  // namespace
 
+// RJ_DEVICES = "all" or a comma-separated list of HIP ordinals ("0,1,2,3"): the context owns
+// those GPUs and rj_execute shards every JoinNode it can across them (one all-to-all over xGMI
+// per relation); unset = the current device only.  Nothing else changes for the harness.
 void* build_context() {
-    rj_context* ctx = nullptr;
-    rj_config   cfg{};
+    rj_context*          ctx = nullptr;
+    rj_config            cfg{};
+    std::vector<int32_t> devs;
     cfg.device = -1;
+    if (const char* e = std::getenv("RJ_DEVICES")) {
+        std::string v(e);
+        if (v == "all") {
+            rj_context* probe = nullptr;
+            rj_config   one{};
+            one.device = -1;
+            if (rj_context_create(&probe, &one) != RJ_OK) fail(nullptr);
+            rj_device_info info{};
+            (void)rj_device_query(probe, &info);
+            rj_context_destroy(probe);
+            for (int32_t d = 0; d < info.device_count; ++d) devs.push_back(d);
+        } else {
+            size_t pos = 0;
+            while (pos < v.size()) {
+                size_t end = v.find(',', pos);
+                if (end == std::string::npos) end = v.size();
+                if (end > pos) devs.push_back(std::atoi(v.substr(pos, end - pos).c_str()));
+                pos = end + 1;
+            }
+        }
+        // a sharded join wants a power-of-two number of ranks
+        size_t n = 1;
+        while (n * 2 <= devs.size()) n *= 2;
+        devs.resize(devs.empty() ? 0 : n);
+    }
+    if (devs.size() > 1) {
+        cfg.n_devices = (int32_t)devs.size();
+        cfg.devices = devs.data();
+    } else if (devs.size() == 1) {
+        cfg.device = devs[0];
+    }
     if (rj_context_create(&ctx, &cfg) != RJ_OK) fail(nullptr);
     return ctx;
 }

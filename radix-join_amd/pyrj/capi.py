@@ -66,6 +66,8 @@ class rj_device_info(C.Structure):
         ("wavefront", C.c_int32),
         ("hbm_bytes", C.c_uint64),
         ("lds_per_cu", C.c_uint64),
+        ("device_count", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -442,6 +444,7 @@ class Context:
             "wavefront": d.wavefront,
             "hbm_bytes": int(d.hbm_bytes),
             "lds_per_cu": int(d.lds_per_cu),
+            "device_count": int(d.device_count),
         }
 
 

@@ -51,3 +51,16 @@ def test_reference_unit_cases_through_cpp_shim():
     assert r.returncode == 0, r.stdout + r.stderr
     for name in ["Empty join", "One line join", "Simple join", "Empty Result", "Multiple same keys", "NULL keys", "Multiple columns", "Build on right"]:
         assert f"ok      {name}" in r.stdout
+
+
+@pytest.mark.gpu
+def test_reference_unit_cases_through_cpp_shim_owning_two_ranks():
+    """RJ_DEVICES=0,0: build_context() owns two (virtual) ranks; rj_execute shards the joins it
+    can (fixed-width, one payload column per side) and answers the others from the first device"""
+    exe = build_exe()
+    env = dict(os.environ, RJ_DEVICES="0,0")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for name in ["Empty join", "One line join", "Simple join", "Empty Result", "Multiple same keys", "NULL keys", "Multiple columns", "Build on right"]:
+        assert f"ok      {name}" in r.stdout
