@@ -19,6 +19,7 @@ void Tuning::from_env() {
     p1_bits = env_int("RJ_TUNE_P1_BITS", p1_bits);
     fine = env_int("RJ_TUNE_FINE", fine);
     pack = env_int("RJ_TUNE_PACK", pack);
+    aos3 = env_int("RJ_TUNE_AOS3", aos3);
     tpg1 = env_int("RJ_TUNE_TPG1", tpg1);
     bcast = env_int("RJ_TUNE_BCAST", bcast);
     diag = env_int("RJ_DIAG", diag);

@@ -166,6 +166,7 @@ struct JoinParams {
     const uint32_t* n_heavy;
     uint32_t        heavy_grid;  // the first heavy_grid workgroups of the launch take heavy tasks
     int32_t         packR, packS; // R.w[0] / S.w[0] is an array of {hashed key, carry} pairs
+    int32_t         aosR, aosS;   // R.w[0] / S.w[0] is an array of 12-byte {hashed key, carry lo, carry hi}
     int32_t         pad;
     unsigned long long* diag;    // phase cycle counters (RJ_DIAG=1 only), else nullptr
 };

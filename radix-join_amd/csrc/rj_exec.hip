@@ -46,6 +46,7 @@ struct Parted {
     uint32_t NP = 0;
     std::vector<uint32_t> pbits;  // radix bits of each pass
     bool     packed = false;      // w[0] = {hashed key, carry} pairs, no w[1]
+    bool     aos3 = false;        // w[0] = 12-byte {hashed key, carry lo, carry hi} tuples, no w[1..2]
     uint64_t n_tuples = 0;        // tuples that went in (NULL keys are dropped on the way: an upper bound)
 };
 
@@ -330,8 +331,15 @@ class Exec {
         const int pack_mode = ctx->tune.pack;
         P.packed = ws ? ws->packed
                       : (!external && KW == 1 && CW == 1 && (pack_mode == 1 || (pack_mode == 2 && fine)));
-        BufP  A[MAX_WORDS], B[MAX_WORDS];
-        Words wa{}, wb{};
+        // one key word + a two-word carry: the LAST pass writes 12-byte tuples into one array
+        // (RJ_TUNE_AOS3=0: key array + pair array, as the earlier passes do)
+        P.aos3 = KW == 1 && CW == 2 && !external && !single_pass && ctx->tune.aos3 != 0;
+        BufP  A[MAX_WORDS], B[MAX_WORDS], AOS;
+        Words wa{}, wb{}, waos{};
+        if (P.aos3) {
+            AOS = ctx->buf(std::max<uint64_t>(n, 1) * 12);
+            waos.w[0] = AOS->as<uint32_t>();
+        }
         for (int a = 0; a < (P.packed ? 1 : P.NW); ++a) {
             // a two-word carry is ONE array of 8-byte pairs (at word KW), key + one carry word
             // one array of pairs altogether (packed)
@@ -341,16 +349,17 @@ class Exec {
                 wa.w[a] = external->w[a];
                 continue;
             }
+            if (P.aos3 && passes == 1) continue;  // the only pass writes the 12-byte array
             A[a] = ctx->buf(n * wbytes);
             wa.w[a] = A[a]->as<uint32_t>();
-            if (passes > 1) {
+            if (passes > (P.aos3 ? 2u : 1u)) {
                 B[a] = ctx->buf(n * wbytes);
                 wb.w[a] = B[a]->as<uint32_t>();
             }
         }
         BufP     seg_off;  // offsets produced by the previous pass
         uint32_t nseg = 1, shift = shift0;
-        Words    cur = ws ? ws->w : Words{}, nxt = wa;
+        Words    cur = ws ? ws->w : Words{}, nxt = (P.aos3 && passes == 1) ? waos : wa;
         bool     cur_is_a = false;
         BufP       fine_off, fine_cursor, coarse_off, coarse_cursor;
         if (fine) {
@@ -424,9 +433,10 @@ class Exec {
                     else
                         launch_pass_scatter_packed(L, cur.w[0], pp, n_groups, nxt.w[0]);
                 } else if (p == 0 && !ws) {
-                    launch_pass_scatter_src(L, src, KW, CW, pp, n_groups, nxt);
+                    launch_pass_scatter_src(L, src, KW, CW, pp, n_groups, nxt, P.aos3 && p + 1 == passes);
                 } else {
-                    launch_pass_scatter_dense(L, cur, P.NW, CW == 2 ? KW : -1, pp, n_groups, nxt);
+                    launch_pass_scatter_dense(L, cur, P.NW, CW == 2 ? KW : -1, pp, n_groups, nxt,
+                                              P.aos3 && p + 1 == passes);
                 }
                 seg_off = off;
                 nseg = (uint32_t)bins;
@@ -434,9 +444,11 @@ class Exec {
                 cur = nxt;
                 cur_is_a = (p % 2 == 0);
                 nxt = cur_is_a ? wb : wa;
+                if (P.aos3 && p + 2 == passes) nxt = waos;  // the next pass is the last one
             }
             P.w = cur;
             for (int a = 0; a < P.NW; ++a) P.wbuf[a] = cur_is_a ? A[a] : B[a];
+            if (P.aos3) P.wbuf[0] = AOS;
             P.off = seg_off;
             P.NP = nseg;
             P.pbits = pbits;
@@ -690,6 +702,8 @@ class Exec {
                 jp.S = PP.w;
                 jp.packR = PB.packed ? 1 : 0;
                 jp.packS = PP.packed ? 1 : 0;
+                jp.aosR = PB.aos3 ? 1 : 0;
+                jp.aosS = PP.aos3 ? 1 : 0;
                 jp.offR = PB.off->as<uint32_t>();
                 jp.offS = PP.off->as<uint32_t>();
                 jp.NP = PB.NP;

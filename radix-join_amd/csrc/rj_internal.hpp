@@ -169,6 +169,7 @@ struct Tuning {
     int p1_bits = 0;      // RJ_TUNE_P1_BITS: radix bits of pass 1 in a two-pass plan (0 = even split)
     int fine = 1;         // RJ_TUNE_FINE: fine (two-digit) histogram for plans <= 2^PT_FINEBITS partitions
     int pack = 1;         // RJ_TUNE_PACK: 0 never, 1 always, 2 fine plans only: {key, carry} pairs
+    int aos3 = 1;         // RJ_TUNE_AOS3: last pass of key + two-word-carry plans writes 12-byte tuples
     int tpg1 = 0;         // RJ_TUNE_TPG1: tiles per group of pass 1 (0 = auto)
     int bcast = 1;        // RJ_TUNE_BCAST: broadcast join for build sides that fit one LDS table
     int diag = 0;         // RJ_DIAG: 1 = join phase stamps, 2 = host-side timings on stderr

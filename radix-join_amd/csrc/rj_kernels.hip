@@ -19,6 +19,7 @@
 #include "rj_kernels.hpp"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace rj {
 
@@ -770,9 +771,16 @@ __global__ __launch_bounds__(PT_MAXF) void k_scan_fine(const uint32_t* fine, uin
 // digit's partition, from the scanned histogram).
 // PAIR >= 0: words PAIR and PAIR+1 (a two-word carry) are written as 8-byte pairs into ONE array,
 // out.w[PAIR] — one output stream and one staging round less than two word arrays.
-template <int NW, class Loader, int PAIR>
+// AOS (NW == 3, PAIR == 1: key + two-word carry, the LAST pass of a plan): the output is ONE array
+// of 12-byte {hashed key, carry lo, carry hi} tuples instead of a key array plus a pair array —
+// one output stream whose runs are 12 bytes per tuple long (a 32-tuple run is 384 contiguous
+// bytes instead of 128 + 256 in two places), and the join reads one stream.  The tile is staged
+// in two halves by sorted position (8192 tuples = 96 KiB of LDS each), so the runs are still
+// those of the whole 16384-tuple tile.
+template <int NW, class Loader, int PAIR, bool AOS>
 __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassParams pp, Words out) {
     static_assert(PAIR < 0 || (PAIR >= 1 && PAIR + 1 < NW), "pair = two carry words behind the key");
+    static_assert(!AOS || (NW == 3 && PAIR == 1), "12-byte tuples: one key word + a two-word carry");
     __shared__ uint2    s_stage2[PT_TILE];  // 128 KiB: a word array uses the first half
     uint32_t* const     s_stage = reinterpret_cast<uint32_t*>(s_stage2);
     __shared__ uint32_t s_cnt[PT_MAXF];
@@ -821,6 +829,38 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassPara
         for (int j = 0; j < PT_ITEMS; ++j)
             if (dr[j] != 0xffffffffu) dr[j] = s_base[dr[j] >> 16] + (dr[j] & 0xffffu);
 
+        if constexpr (AOS) {
+            constexpr uint32_t HALF = PT_TILE / 2;
+            uint2* const       s_p = s_stage2;                                      // [HALF] carries
+            uint32_t* const    s_k = reinterpret_cast<uint32_t*>(s_stage2 + HALF);  // [HALF] keys
+            if (threadIdx.x < F) s_delta[threadIdx.x] = run - ex;  // global index = delta + sorted position
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int j = 0; j < PT_ITEMS; ++j) {
+                    const uint32_t lp = dr[j] - h * HALF;  // (no tuple: 0xffffffff stays out of range)
+                    if (lp < HALF) {
+                        s_k[lp] = w[j][0];
+                        s_p[lp] = make_uint2(w[j][1], w[j][2]);
+                    }
+                }
+                lds_barrier();
+#pragma unroll
+                for (int k = 0; k < PT_ITEMS / 2; ++k) {
+                    const uint32_t i = k * PT_THREADS + threadIdx.x, gi = h * HALF + i;
+                    if (gi < total) {
+                        const uint32_t v = s_k[i];
+                        const uint2    c = s_p[i];
+                        uint32_t*      o = out.w[0] + (size_t)(s_delta[(v >> pp.shift) & mask] + gi) * 3u;
+                        o[0] = v;
+                        o[1] = c.x;
+                        o[2] = c.y;
+                    }
+                }
+                lds_barrier();
+            }
+            continue;
+        }
         // word 0 (the hashed key): stage in digit order, copy out.  The digit of a staged
         // key is recomputed from the key itself, and the global destination of each LDS
         // position is kept in a register for the remaining word arrays.
@@ -1086,10 +1126,47 @@ __global__ __launch_bounds__(jn_threads(TG ? 2 : KW + CWR), jn_min_waves(TG ? 2 
                       : ((j / 4) * TH + threadIdx.x) * 4 + (j % 4);
     };
     constexpr bool packR = (PK & 1) != 0, packS = (PK & 2) != 0;
+    constexpr bool aosR = (PK & 4) != 0, aosS = (PK & 8) != 0;
+    static_assert(!aosR || (KW == 1 && CWR == 2), "12-byte build tuples: key + two-word carry");
+    static_assert(!aosS || (KW == 1 && CWS == 2), "12-byte probe tuples: key + two-word carry");
+    // four consecutive 12-byte tuples = three 16-byte loads (dword aligned)
+    auto load_aos3 = [&](const uint32_t* base, uint32_t n, auto& regs, auto n_items) {
+        constexpr int NI = decltype(n_items)::value;
+#pragma unroll
+        for (int v = 0; v < NI / 4; ++v) {
+            const uint32_t  i0 = (v * TH + threadIdx.x) * 4;
+            const uint32_t* p = base + (size_t)i0 * 3;
+            if (i0 + 3 < n) {
+                const u32x4a x = *reinterpret_cast<const u32x4a*>(p), y = *reinterpret_cast<const u32x4a*>(p + 4),
+                             z = *reinterpret_cast<const u32x4a*>(p + 8);
+                regs[4 * v + 0][0] = x[0];
+                regs[4 * v + 0][1] = x[1];
+                regs[4 * v + 0][2] = x[2];
+                regs[4 * v + 1][0] = x[3];
+                regs[4 * v + 1][1] = y[0];
+                regs[4 * v + 1][2] = y[1];
+                regs[4 * v + 2][0] = y[2];
+                regs[4 * v + 2][1] = y[3];
+                regs[4 * v + 2][2] = z[0];
+                regs[4 * v + 3][0] = z[1];
+                regs[4 * v + 3][1] = z[2];
+                regs[4 * v + 3][2] = z[3];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) regs[4 * v + e][a] = i0 + e < n ? p[e * 3 + a] : 0u;
+            }
+        }
+    };
     static_assert(!packR || (KW == 1 && CWR == 1), "packed build side: key + one carry word");
     static_assert(!packS || (KW == 1 && CWS == 1), "packed probe side: key + one carry word");
     auto load_build = [&](uint32_t rc, uint32_t rn) {
         constexpr int LW = RW;
+        if constexpr (aosR) {
+            load_aos3(jp.R.w[0] + (size_t)rc * 3, rn, rw, std::integral_constant<int, RPT>{});
+            return;
+        }
         if constexpr (packR) {
             {
                 const uint2* rp = reinterpret_cast<const uint2*>(jp.R.w[0]) + rc;
@@ -1154,6 +1231,10 @@ __global__ __launch_bounds__(jn_threads(TG ? 2 : KW + CWR), jn_min_waves(TG ? 2 
         }
     };
     auto load_probe = [&](uint32_t sc, uint32_t sn) {
+        if constexpr (aosS) {
+            load_aos3(jp.S.w[0] + (size_t)sc * 3, sn, sw, std::integral_constant<int, SPT>{});
+            return;
+        }
         if constexpr (packS) {
             {
                 const uint2* sp = reinterpret_cast<const uint2*>(jp.S.w[0]) + sc;
@@ -1930,13 +2011,19 @@ template <int KW, int CW>
 static void scatter_src_t(const Launch& L, const TupleSrc& src, const PassParams& pp,
                           uint32_t n_groups, const Words& out) {
     SrcLoader<KW, CW> ld{src};
-    RJ_KLAUNCH(L, "pass1_scatter", (k_pass_scatter<KW + CW, SrcLoader<KW, CW>, (CW == 2 ? KW : -1)>),
+    RJ_KLAUNCH(L, "pass1_scatter", (k_pass_scatter<KW + CW, SrcLoader<KW, CW>, (CW == 2 ? KW : -1), false>),
                n_groups, PT_THREADS, ld, pp, out);
 }
 
 void launch_pass_scatter_src(const Launch& L, const TupleSrc& src, int key_words, int carry_words,
-                             const PassParams& pp, uint32_t n_groups, const Words& out) {
+                             const PassParams& pp, uint32_t n_groups, const Words& out, bool aos3) {
     if (!n_groups) return;
+    if (aos3) {
+        if (key_words != 1 || carry_words != 2) launch_failed("pass1_scatter", "12-byte tuples need KW=1, CW=2", true);
+        SrcLoader<1, 2> ld{src};
+        RJ_KLAUNCH(L, "pass1_scatter", (k_pass_scatter<3, SrcLoader<1, 2>, 1, true>), n_groups, PT_THREADS, ld, pp, out);
+        return;
+    }
     switch (key_words * 10 + carry_words) {
     case 10: scatter_src_t<1, 0>(L, src, pp, n_groups, out); break;
     case 11: scatter_src_t<1, 1>(L, src, pp, n_groups, out); break;
@@ -1956,27 +2043,33 @@ void launch_pass_hist_dense(const Launch& L, const Words& in, const PassParams& 
 }
 
 void launch_pass_scatter_dense(const Launch& L, const Words& in, int n_words, int pair_word,
-                               const PassParams& pp, uint32_t n_groups, const Words& out) {
+                               const PassParams& pp, uint32_t n_groups, const Words& out, bool aos3) {
     if (!n_groups) return;
+    if (aos3) {
+        if (n_words != 3 || pair_word != 1) launch_failed("pass2_scatter", "12-byte tuples need KW=1, CW=2", true);
+        RJ_KLAUNCH(L, "pass2_scatter", (k_pass_scatter<3, DenseLoaderT<1>, 1, true>), n_groups, PT_THREADS,
+                   DenseLoaderT<1>{in}, pp, out);
+        return;
+    }
     switch (n_words * 10 + (pair_word < 0 ? 9 : pair_word)) {
     case 19:
-        RJ_KLAUNCH(L, "pass2_scatter", (k_pass_scatter<1, DenseLoader, -1>), n_groups, PT_THREADS,
+        RJ_KLAUNCH(L, "pass2_scatter", (k_pass_scatter<1, DenseLoader, -1, false>), n_groups, PT_THREADS,
                    DenseLoader{in}, pp, out);
         break;
     case 29:
-        RJ_KLAUNCH(L, "pass2_scatter", (k_pass_scatter<2, DenseLoader, -1>), n_groups, PT_THREADS,
+        RJ_KLAUNCH(L, "pass2_scatter", (k_pass_scatter<2, DenseLoader, -1, false>), n_groups, PT_THREADS,
                    DenseLoader{in}, pp, out);
         break;
     case 39:
-        RJ_KLAUNCH(L, "pass2_scatter", (k_pass_scatter<3, DenseLoader, -1>), n_groups, PT_THREADS,
+        RJ_KLAUNCH(L, "pass2_scatter", (k_pass_scatter<3, DenseLoader, -1, false>), n_groups, PT_THREADS,
                    DenseLoader{in}, pp, out);
         break;
     case 31:  // key + carry pair
-        RJ_KLAUNCH(L, "pass2_scatter", (k_pass_scatter<3, DenseLoaderT<1>, 1>), n_groups, PT_THREADS,
+        RJ_KLAUNCH(L, "pass2_scatter", (k_pass_scatter<3, DenseLoaderT<1>, 1, false>), n_groups, PT_THREADS,
                    DenseLoaderT<1>{in}, pp, out);
         break;
     case 42:  // two key words + carry pair
-        RJ_KLAUNCH(L, "pass2_scatter", (k_pass_scatter<4, DenseLoaderT<2>, 2>), n_groups, PT_THREADS,
+        RJ_KLAUNCH(L, "pass2_scatter", (k_pass_scatter<4, DenseLoaderT<2>, 2, false>), n_groups, PT_THREADS,
                    DenseLoaderT<2>{in}, pp, out);
         break;
     default: launch_failed("pass2_scatter", "no kernel for this word layout", true);
@@ -2023,7 +2116,7 @@ static bool join_tagged(int key_words, int cw_build, const JoinParams& jp) {
 template <int KW, int CWR, int CWS, int PK>
 static void join_pk(const Launch& L, const JoinParams& jp, uint32_t grid) {
     const char* name = "join_build_probe";
-    if constexpr (KW == 1 && CWR == 2 && PK == 0) {
+    if constexpr (KW == 1 && CWR == 2 && (PK & 3) == 0) {
         const bool p366 = CWS == 2 && jp.key.mode == ST_PAGED32 && jp.bc.mode == ST_PAGED64 &&
                           jp.pc.mode == ST_PAGED64;
         if (join_tagged(KW, CWR, jp)) {
@@ -2066,20 +2159,26 @@ static void join_pk(const Launch& L, const JoinParams& jp, uint32_t grid) {
     RJ_KLAUNCH(L, name, (k_join<KW, CWR, CWS, OM_GENERIC, PK, 0>), grid, jn_threads(KW + CWR), jp);
 }
 
-// the packed variants exist only for the shapes that can be packed
+// the packed / 12-byte variants exist only for the shapes that can have them
 template <int KW, int CWR, int CWS>
 static void join_t(const Launch& L, const JoinParams& jp, uint32_t grid) {
-    constexpr int CAN = (KW == 1 && CWR == 1 ? 1 : 0) | (KW == 1 && CWS == 1 ? 2 : 0);
-    const int     pk = (jp.packR ? 1 : 0) | (jp.packS ? 2 : 0);
-    if constexpr (CAN == 3) {
-        if (pk == 3) return join_pk<KW, CWR, CWS, 3>(L, jp, grid);
-        if (pk == 1) return join_pk<KW, CWR, CWS, 1>(L, jp, grid);
-        if (pk == 2) return join_pk<KW, CWR, CWS, 2>(L, jp, grid);
-    } else if constexpr (CAN == 1) {
-        if (pk == 1) return join_pk<KW, CWR, CWS, 1>(L, jp, grid);
-    } else if constexpr (CAN == 2) {
-        if (pk == 2) return join_pk<KW, CWR, CWS, 2>(L, jp, grid);
-    }
+    constexpr int CAN = (KW == 1 && CWR == 1 ? 1 : 0) | (KW == 1 && CWS == 1 ? 2 : 0) |
+                        (KW == 1 && CWR == 2 ? 4 : 0) | (KW == 1 && CWS == 2 ? 8 : 0);
+    const int     pk = (jp.packR ? 1 : 0) | (jp.packS ? 2 : 0) | (jp.aosR ? 4 : 0) | (jp.aosS ? 8 : 0);
+    if (pk & ~CAN) launch_failed("join_build_probe", "tuple layout flags do not fit the key/carry widths", true);
+#define RJ_JOIN_PK(V)                 \
+    if constexpr ((CAN & (V)) == (V)) \
+        if (pk == (V)) return join_pk<KW, CWR, CWS, (V)>(L, jp, grid);
+    RJ_JOIN_PK(1)
+    RJ_JOIN_PK(2)
+    RJ_JOIN_PK(3)
+    RJ_JOIN_PK(4)
+    RJ_JOIN_PK(8)
+    RJ_JOIN_PK(12)
+    RJ_JOIN_PK(6)
+    RJ_JOIN_PK(9)
+#undef RJ_JOIN_PK
+    if (pk != 0) launch_failed("join_build_probe", "no kernel for this tuple layout", true);
     join_pk<KW, CWR, CWS, 0>(L, jp, grid);
 }
 

@@ -60,15 +60,17 @@ void launch_fine_hist_words(const Launch& L, const Words& in, bool packed, uint3
                             uint32_t b1, uint32_t b2, uint32_t grid, uint32_t* fine);
 void launch_scan_fine(const Launch& L, const uint32_t* fine, uint32_t F1, uint32_t F2,
                       uint32_t* off2, uint32_t* cursor2, uint32_t* off1, uint32_t* cursor1);
+// aos3 (key_words == 1, carry_words == 2, last pass of a plan): out.w[0] receives 12-byte
+// {hashed key, carry lo, carry hi} tuples instead of a key array + a pair array
 void launch_pass_scatter_src(const Launch& L, const TupleSrc& src, int key_words, int carry_words,
-                             const PassParams& pp, uint32_t n_groups, const Words& out);
+                             const PassParams& pp, uint32_t n_groups, const Words& out, bool aos3 = false);
 // Dense pass: re-partition every segment of already partitioned word arrays.
 void launch_pass_hist_dense(const Launch& L, const Words& in, const PassParams& pp,
                             uint32_t n_groups);
 // pair_word >= 0: words pair_word / pair_word+1 (a two-word carry) live as 8-byte pairs in
 // in.w[pair_word] / out.w[pair_word] (what every pass writes for two-word carries); else -1
 void launch_pass_scatter_dense(const Launch& L, const Words& in, int n_words, int pair_word,
-                               const PassParams& pp, uint32_t n_groups, const Words& out);
+                               const PassParams& pp, uint32_t n_groups, const Words& out, bool aos3 = false);
 
 // Packed layout ({hashed key, carry} pairs in one array) for one key word + one carry word.
 void launch_pass_hist_packed(const Launch& L, const uint32_t* in_pairs, const PassParams& pp,
