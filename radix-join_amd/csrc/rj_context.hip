@@ -23,6 +23,7 @@ void Tuning::from_env() {
     tpg1 = env_int("RJ_TUNE_TPG1", tpg1);
     bcast = env_int("RJ_TUNE_BCAST", bcast);
     diag = env_int("RJ_DIAG", diag);
+    varchar_dev_rows = env_int("RJ_TUNE_VARCHAR_DEV", varchar_dev_rows);
     sync_upload = env_int("RJ_SYNC_UPLOAD", sync_upload);
 }
 

@@ -171,6 +171,19 @@ struct JoinParams {
     unsigned long long* diag;    // phase cycle counters (RJ_DIAG=1 only), else nullptr
 };
 
+// ---- VARCHAR materialisation on the device (rj_varchar_dev.hip) ----------------------------
+struct VcRow {
+    uint32_t page;  // source page index (first page of a long string's chain)
+    uint32_t beg;   // byte offset of the first character inside the page; 0xffffffff = long string
+    uint32_t len;   // characters; 0xffffffff = NULL
+};
+struct VcPage {
+    uint32_t first;  // first result row of the page (the row itself for long-string pieces)
+    uint32_t nr;     // rows of a normal page
+    uint32_t kind;   // 0 = normal page, 1 + k = piece k of a long string
+};
+constexpr uint32_t VC_CHUNK = 512;  // result rows per fill-rule chunk (one lane walks one chunk)
+
 // ---- Broadcast join (build side fits ONE LDS table): no partitioning at all --------------
 struct BcastParams {
     TupleSrc        R, S;        // build / probe tuples straight from the child columns

@@ -875,11 +875,56 @@ class Exec {
         const TableColumn& tc = t->cols[src.vc_col];
         const bool diag = ctx->tune.diag >= 2;
         auto       tv0 = std::chrono::steady_clock::now();
+        auto       key = std::make_pair(src.vc_table, src.vc_col);
+        if (ctx->tune.varchar_dev_rows > 0 && n >= (uint64_t)ctx->tune.varchar_dev_rows &&
+            tc.vc_pages.size() <= 0xfffffff0ull && t->num_rows <= 0xfffffff0ull) {
+            // ---- large result: gather + encode on the device (rj_varchar_dev.hip)
+            auto it = vc_dir_.find(key);
+            if (it == vc_dir_.end()) {
+                it = vc_dir_.emplace(key, std::vector<uint64_t>()).first;
+                varchar_dir_build(tc.vc_pages.data(), tc.vc_pages.size(), t->num_rows, it->second);
+            }
+            const uint32_t npg = (uint32_t)tc.vc_pages.size();
+            if (!tc.vc_dev) {  // the base column's pages + row directory go to HBM once per table
+                tc.vc_dev = ctx->buf(std::max<uint64_t>(npg, 1) * PAGE_BYTES);
+                upload_host_pages(ctx, tc.vc_pages.data(), npg, tc.vc_dev->as<uint8_t>());
+                std::vector<uint32_t> dir32(it->second.begin(), it->second.end());
+                tc.vc_dev_dir = ctx->buf(dir32.size() * 4);
+                RJ_HIP(hipMemcpyAsync(tc.vc_dev_dir->p, dir32.data(), dir32.size() * 4, hipMemcpyHostToDevice,
+                                      ctx->stream));
+                ctx->sync();  // dir32 is a local
+            }
+            auto           tv1 = std::chrono::steady_clock::now();
+            const uint32_t nr = (uint32_t)n, chunks = (nr + VC_CHUNK - 1) / VC_CHUNK;
+            BufP           vrows = ctx->buf((uint64_t)nr * sizeof(VcRow));
+            BufP           pcnt = ctx->buf((uint64_t)chunks * 4), pbase = ctx->buf(((uint64_t)chunks + 1) * 4);
+            launch_vc_resolve(L, tc.vc_dev->as<uint8_t>(), npg, tc.vc_dev_dir->as<uint32_t>(), dev_rowids, nr,
+                              vrows->as<VcRow>());
+            launch_vc_walk(L, vrows->as<VcRow>(), nr, pcnt->as<uint32_t>(), nullptr, nullptr);
+            launch_scan_bins(L, pcnt->as<uint32_t>(), chunks, pbase->as<uint32_t>(), nullptr);
+            uint32_t n_out = 0;
+            RJ_HIP(hipMemcpyAsync(&n_out, pbase->as<uint32_t>() + chunks, 4, hipMemcpyDeviceToHost, ctx->stream));
+            ctx->sync();
+            BufP plist = ctx->buf(std::max<uint64_t>(n_out, 1) * sizeof(VcPage));
+            rc.dev_pages = ctx->buf(std::max<uint64_t>(n_out, 1) * PAGE_BYTES);
+            launch_vc_walk(L, vrows->as<VcRow>(), nr, pcnt->as<uint32_t>(), pbase->as<uint32_t>(),
+                           plist->as<VcPage>());
+            launch_vc_encode(L, tc.vc_dev->as<uint8_t>(), npg, vrows->as<VcRow>(), plist->as<VcPage>(), n_out,
+                             rc.dev_pages->as<uint8_t>());
+            rc.n_pages = n_out;
+            if (diag) {
+                ctx->sync();
+                auto tv2 = std::chrono::steady_clock::now();
+                auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+                fprintf(stderr, "[rj host]   varchar col on the device: %llu rows -> %u pages, source pages in HBM %.2f ms, resolve+walk+encode %.2f ms\n",
+                        (unsigned long long)n, n_out, ms(tv0, tv1), ms(tv1, tv2));
+            }
+            return;
+        }
         std::vector<uint32_t> ids(n);
         RJ_HIP(hipMemcpyAsync(ids.data(), dev_rowids, n * 4, hipMemcpyDeviceToHost, ctx->stream));
         ctx->sync();
         auto tv1 = std::chrono::steady_clock::now();
-        auto key = std::make_pair(src.vc_table, src.vc_col);
         auto it = vc_dir_.find(key);
         if (it == vc_dir_.end()) {
             it = vc_dir_.emplace(key, std::vector<uint64_t>()).first;

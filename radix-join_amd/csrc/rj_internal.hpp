@@ -131,6 +131,9 @@ struct TableColumn {
     // Plan's inputs outlive the call)
     std::vector<uint8_t>        host_pages;
     std::vector<const uint8_t*> vc_pages;
+    // VARCHAR pages + row directory in HBM, uploaded on first use by a large root output
+    // (device-side materialisation, rj_varchar_dev.hip)
+    mutable BufP vc_dev, vc_dev_dir;
     bool                        skipped = false;  // not referenced by the plan: never uploaded
 };
 
@@ -173,6 +176,8 @@ struct Tuning {
     int tpg1 = 0;         // RJ_TUNE_TPG1: tiles per group of pass 1 (0 = auto)
     int bcast = 1;        // RJ_TUNE_BCAST: broadcast join for build sides that fit one LDS table
     int diag = 0;         // RJ_DIAG: 1 = join phase stamps, 2 = host-side timings on stderr
+    int varchar_dev_rows = 200000;  // RJ_TUNE_VARCHAR_DEV: root VARCHAR columns of at least this many
+                                    // rows are gathered + encoded on the device (0 = never)
     int sync_upload = 0;  // RJ_SYNC_UPLOAD: upload every input before the plan starts
     void from_env();
 };
@@ -270,6 +275,9 @@ class AsyncUpload : public TableFetch {
 Table* table_adopt(Context* ctx, uint64_t num_rows, uint64_t n_cols, const int32_t* types,
                    const void* const* dev_pages, const uint64_t* n_pages);
 void   result_copy_pages(Result* r, uint64_t col, void* const* dst, uint64_t n_dst);
+// n_pages individually allocated host pages -> contiguous page images at `dev` (pinned staging,
+// 32 MiB chunks, on the context's stream; synchronises)
+void   upload_host_pages(Context* ctx, const uint8_t* const* pages, uint64_t n_pages, uint8_t* dev);
 // rj_execute on a context that owns several devices: shard the host inputs by row ranges, run
 // the plan sharded and gather the ranks' pages into one result.  nullptr = this plan / these
 // inputs cannot be sharded (the caller runs them on the first device).

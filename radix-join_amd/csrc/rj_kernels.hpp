@@ -104,4 +104,15 @@ void launch_finish_streams(const Launch& L, uint8_t* const* pages, const int* wi
 void launch_encode_nullable(const Launch& L, const uint8_t* values, const uint8_t* valid,
                             uint64_t n_rows, int width, uint8_t* pages);
 
+// ---- VARCHAR gather + page encode on the device (replaces, for large results, the string half
+//      of Table::to_columnar, reference src/build_table.cpp:595-677)
+void launch_vc_resolve(const Launch& L, const uint8_t* pages, uint32_t n_pages, const uint32_t* row_base,
+                       const uint32_t* rowids, uint32_t n, VcRow* out);
+// page_out == nullptr: pages_in_chunk[c] = pages of chunk c; else the pages are written to
+// page_out[page_base[c] ...]
+void launch_vc_walk(const Launch& L, const VcRow* rows, uint32_t n, uint32_t* pages_in_chunk,
+                    const uint32_t* page_base, VcPage* page_out);
+void launch_vc_encode(const Launch& L, const uint8_t* pages, uint32_t n_pages, const VcRow* rows,
+                      const VcPage* plist, uint32_t n_out_pages, uint8_t* out);
+
 }  // namespace rj

@@ -247,6 +247,25 @@ void table_fill(Table* t, const rj_input* in, UploadLane& lane) {
 
 }  // namespace
 
+void upload_host_pages(Context* ctx, const uint8_t* const* pages, uint64_t n_pages, uint8_t* dev) {
+    if (!n_pages) return;
+    UploadLane lane(ctx->stream, ctx->staging(2 * CHUNK_PAGES * PAGE_BYTES));
+    for (uint64_t p0 = 0; p0 < n_pages; p0 += CHUNK_PAGES) {
+        const uint64_t np = std::min<uint64_t>(CHUNK_PAGES, n_pages - p0);
+        uint8_t*       s = lane.stage + (size_t)lane.half * CHUNK_PAGES * PAGE_BYTES;
+        if (lane.used[lane.half]) RJ_HIP(hipEventSynchronize(lane.ev[lane.half]));
+        parallel_for(np, 256, [&](size_t b, size_t e) {
+            for (size_t p = b; p < e; ++p) copy_page(s + p * PAGE_BYTES, pages[p0 + p]);
+            copy_pages_fence();
+        });
+        RJ_HIP(hipMemcpyAsync(dev + p0 * PAGE_BYTES, s, np * PAGE_BYTES, hipMemcpyHostToDevice, lane.stream));
+        RJ_HIP(hipEventRecord(lane.ev[lane.half], lane.stream));
+        lane.used[lane.half] = true;
+        lane.half ^= 1;
+    }
+    RJ_HIP(hipStreamSynchronize(lane.stream));
+}
+
 Table* table_upload(Context* ctx, const rj_input* in, const std::vector<bool>* col_used,
                     bool borrow_varchar) {
     std::unique_ptr<Table> t(table_prepare(ctx, in, col_used, borrow_varchar));
@@ -411,7 +430,7 @@ void result_copy_pages(Result* r, uint64_t col, void* const* dst, uint64_t n_dst
     ResultColumn& c = r->cols[col];
     if (n_dst < c.n_pages) throw_fmt(RJ_ERR_ARG, "destination has too few pages");
     if (c.n_pages == 0) return;
-    if (c.type == RJ_VARCHAR || (!c.dev_pages && c.more.empty())) {
+    if (!c.dev_pages && c.more.empty()) {  // host-encoded pages (small VARCHAR results)
         const uint8_t* src = c.host_pages.data();
         parallel_for(c.n_pages, 256, [&](size_t b, size_t e) {
             for (size_t p = b; p < e; ++p) memcpy(dst[p], src + p * PAGE_BYTES, PAGE_BYTES);
