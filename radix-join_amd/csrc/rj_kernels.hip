@@ -164,10 +164,24 @@ __global__ __launch_bounds__(256) void k_page_headers(const uint8_t* pages, uint
     const uint32_t nb = (nr + 7) / 8;
     const uint8_t* bm = page + PAGE_BYTES - nb;
     bool           ones = true;
-    for (uint32_t k = lane; k < nb; k += 64) {
-        const uint32_t rem = nr - k * 8u;
-        const uint32_t want = rem >= 8 ? 0xffu : ((1u << rem) - 1u);
-        ones = ones && ((bm[k] & want) == want);
+    // full pages: 248 bitmap bytes at a dword boundary (INT32) or 126 at a halfword boundary
+    // (INT64/FP64) — one load per lane; anything else byte by byte
+    const uint32_t boff = PAGE_BYTES - nb;
+    if ((nr & 31u) == 0 && (boff & 3u) == 0) {
+        for (uint32_t k = lane; k < nb / 4; k += 64)
+            ones = ones && reinterpret_cast<const uint32_t*>(bm)[k] == 0xffffffffu;
+    } else if ((boff & 1u) == 0 && (nb & 1u) == 0) {
+        for (uint32_t k = lane; k < nb / 2; k += 64) {
+            const uint32_t rem = nr - k * 16u;
+            const uint32_t want = rem >= 16 ? 0xffffu : ((1u << rem) - 1u);
+            ones = ones && ((uint32_t)reinterpret_cast<const uint16_t*>(bm)[k] & want) == want;
+        }
+    } else {
+        for (uint32_t k = lane; k < nb; k += 64) {
+            const uint32_t rem = nr - k * 8u;
+            const uint32_t want = rem >= 8 ? 0xffu : ((1u << rem) - 1u);
+            ones = ones && ((bm[k] & want) == want);
+        }
     }
     const bool all_ones = __ballot(!ones) == 0;
     if (lane != 0) return;
