@@ -224,15 +224,9 @@ def job_plan_ms(dev_index, queries=("1a", "13d"), repeat=3):
     return out
 
 
-def cpu_baseline(sample_rows):
-    """The CPU oracle (port of the reference's execute path) on a bounded sample of the headline
-    workload's shape (unique INT32 build keys, Zipf-0.9 probe keys, INT64 payloads), on this
-    box's host cores (single thread: the reference's 8-thread run was slower than 1 thread,
-    SURVEY.md §6)."""
-    import _oracle
-
-    rng = np.random.default_rng(1)
-    n = sample_rows
+def _config3_sample(n, seed=1):
+    """unique INT32 build keys, Zipf-0.9 probe keys over them, INT64 payloads (numpy)"""
+    rng = np.random.default_rng(seed)
     rk = rng.permutation(n).astype(np.int32)
     w = 1.0 / np.arange(1, n + 1, dtype=np.float64) ** 0.9
     cdf = np.cumsum(w)
@@ -240,21 +234,77 @@ def cpu_baseline(sample_rows):
     ranks = np.searchsorted(cdf, rng.random(n), side="right").clip(max=n - 1).astype(np.int64)
     del w, cdf
     sk = ((ranks * 7919 + 13) % n).astype(np.int32)
+    return rk, sk
+
+
+_CPU_SHARDS = None  # inherited by the forked workers (no pickling of the arrays)
+
+
+def _cpu_worker(args):
+    shard, barrier = args
+    import _oracle
+
+    rk, rp, sk, sp = _CPU_SHARDS[shard]
+    p = wl.join_plan(pl.INT64)
+    p.new_input(pl.make_table([(pl.INT32, rk), (pl.INT64, rp)]))
+    p.new_input(pl.make_table([(pl.INT32, sk), (pl.INT64, sp)]))
+    _oracle.lib()
+    barrier.wait()  # every worker starts its join at the same moment
+    t0 = time.perf_counter()
+    res = _oracle.execute(p)
+    dt = time.perf_counter() - t0
+    assert res.num_rows == sk.shape[0]
+    return sk.shape[0], dt
+
+
+def cpu_baseline(sample_rows, workers=0):
+    """The CPU oracle (port of the reference's execute path, oracle/rjo_oracle.c) on a bounded
+    sample of the headline workload's shape (unique INT32 build keys, Zipf-0.9 probe keys, INT64
+    payloads), on this box's host cores.  The port is single-threaded, as is the fastest
+    configuration of the reference itself (its 8-thread run was slower than 1 thread, SURVEY.md
+    §6); the all-core figure runs one instance per core on hash-disjoint shards of the same
+    sample (key mod P: PK-FK shards join independently), all started together.
+    Must run before this process touches the GPU (the workers are forked)."""
+    global _CPU_SHARDS
+    import multiprocessing as mp
+
+    import _oracle
+
+    n = sample_rows
+    rk, sk = _config3_sample(n)
     pay = np.arange(n, dtype=np.int64) * wl.PAY_MUL
+    # ---- one thread, the whole sample
     p = wl.join_plan(pl.INT64)
     p.new_input(pl.make_table([(pl.INT32, rk), (pl.INT64, pay)]))
     p.new_input(pl.make_table([(pl.INT32, sk), (pl.INT64, pay)]))
     _oracle.lib()
     t0 = time.perf_counter()
     res = _oracle.execute(p)
-    dt = time.perf_counter() - t0
+    dt1 = time.perf_counter() - t0
     assert res.num_rows == n
+    del res, p
+    # ---- P instances on hash-disjoint shards (16 = the box's CPU share for one GPU)
+    P = workers or min(16, os.cpu_count() or 1)
+    _CPU_SHARDS = []
+    for s in range(P):
+        mb, ms = (rk % P) == s, (sk % P) == s
+        _CPU_SHARDS.append((rk[mb], pay[mb], sk[ms], pay[ms]))
+    ctx = mp.get_context("fork")
+    with mp.Manager() as mgr:
+        barrier = mgr.Barrier(P)
+        with ctx.Pool(P) as pool:
+            outs = pool.map(_cpu_worker, [(s, barrier) for s in range(P)])
+    _CPU_SHARDS = None
+    rows = sum(o[0] for o in outs)
+    wall = max(o[1] for o in outs)
     return {
-        "value": n / dt,
+        "value": rows / wall,
         "unit": "probe tuples/s",
-        "cores": 1,
+        "cores": P,
         "kind": "port",
-        "sample": f"{n} x {n} INT32 keys (Zipf-0.9 probe), INT64 payloads, same plan, oracle/rjo_oracle.c incl. page decode+encode, {dt:.1f} s",
+        "sample": f"{n} x {n} INT32 keys (Zipf-0.9 probe), INT64 payloads, same plan, oracle/rjo_oracle.c incl. page decode+encode: "
+        f"{P} single-threaded instances on key-mod-{P} shards started together, slowest {wall:.1f} s",
+        "single_thread": {"value": n / dt1, "cores": 1, "seconds": dt1, "sample": f"the whole {n} x {n} sample in one instance"},
     }
 
 
@@ -279,6 +329,14 @@ def main():
     distributed = world > 1 or os.environ.get("RJ_BENCH_FORCE_DIST") == "1"
     if args.gpus != world and distributed:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    cpu = None
+    if not distributed and not args.no_cpu_baseline:
+        # first, while this process has not touched the GPU yet (the workers are forked); it is
+        # a reported baseline on the host cores, not part of any timed GPU region
+        if torch.cuda.device_count() == 0:
+            raise SystemExit("bench.py needs a GPU: the HIP path is the product, there is no CPU fallback")
+        cpu = cpu_baseline(args.cpu_sample)
+        cpu["host_cores_available"] = os.cpu_count()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path is the product, there is no CPU fallback")
     dev_index = local_rank % torch.cuda.device_count()
@@ -334,9 +392,8 @@ def main():
             }
         out["configs"] = extras
         out["plan_ms"] = job_plan_ms(dev_index)
-    if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
-        out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
     print(json.dumps(out))
 
 
