@@ -24,6 +24,7 @@ void Tuning::from_env() {
     bcast = env_int("RJ_TUNE_BCAST", bcast);
     diag = env_int("RJ_DIAG", diag);
     varchar_dev_rows = env_int("RJ_TUNE_VARCHAR_DEV", varchar_dev_rows);
+    vkey_hash_bits = env_int("RJ_DEBUG_VKEY_HASH_BITS", vkey_hash_bits);
     sync_upload = env_int("RJ_SYNC_UPLOAD", sync_upload);
 }
 

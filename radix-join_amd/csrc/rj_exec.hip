@@ -504,6 +504,17 @@ class Exec {
             size_t   lw = 0, rw = 0;
             int      KW = 1;
             uint64_t cap_hint = 0;  // rows the output streams are sized for at the first attempt
+            // VARCHAR join keys (hash_join_omp<std::string>, src/execute.cpp:278): each side's
+            // relation is copied with one extra column — the 64-bit FNV-1a of the key strings —
+            // which the join runs on; `rows` remembers where every string sits for the
+            // byte-for-byte check of the joined pairs
+            bool vkey = false;
+            struct VKey {
+                Rel            rel;
+                BufP           rows, hash, valid;
+                const uint8_t* pages = nullptr;
+                uint32_t       n_pages = 0;
+            } vk[2];  // [0] = left, [1] = right
             Side&    bs() { return build_left ? ls : rs; }
             Side&    ps() { return build_left ? rs : ls; }
         };
@@ -531,12 +542,10 @@ class Exec {
             const DCol& bk = st.bs().rel->cols[st.bs().key_col];
             const DCol& pk = st.ps().rel->cols[st.ps().key_col];
             // KeyType = build side's key type (:271-273)
-            if (bk.type == RJ_VARCHAR)
-                throw_fmt(RJ_ERR_UNSUPPORTED,
-                          "VARCHAR join keys are not supported on the GPU path (never a JOB join key)");
             if (bk.type < RJ_INT32 || bk.type > RJ_VARCHAR) throw_fmt(RJ_ERR_ARG, "Unsupported join type");
             // probe values of another variant alternative are never valid (:65-71)
             st.type_mismatch = pk.type != bk.type;
+            st.vkey = bk.type == RJ_VARCHAR && !st.type_mismatch;
             st.KW = bk.type == RJ_INT32 ? 1 : 2;
             st.f64 = bk.type == RJ_FP64;
             // matching keys are bit-identical on both sides (FP64 included: bit-pattern equality,
@@ -546,13 +555,16 @@ class Exec {
                 bool  is_left = js.out_idx[k] < lw;
                 Side& s = is_left ? ls : rs;
                 int   c = (int)(is_left ? js.out_idx[k] : js.out_idx[k] - lw);
-                if ((uint64_t)c == s.key_col)
+                if ((uint64_t)c == s.key_col && !st.vkey)
                     st.need_key_stream = true;
                 else
-                    s.need.insert(c);
+                    s.need.insert(c);  // (a VARCHAR key column is gathered like any other column)
             }
             for (Side* s : {&ls, &rs}) {
-                if (s->need.empty()) {
+                if (st.vkey) {  // both row indices are needed for the string comparison of the pairs
+                    s->carry_mode = CARRY_ROWIDX;
+                    s->CW = 1;
+                } else if (s->need.empty()) {
                     s->carry_mode = CARRY_NONE;
                     s->CW = 0;
                 } else if (s->need.size() == 1 && s->rel->cols[*s->need.begin()].valid == nullptr) {
@@ -605,6 +617,7 @@ class Exec {
             JoinState st;
             join_prepare(left, right, js, root_res != nullptr, st);
             if (st.type_mismatch) return empty_rel(js, root_res);
+            if (st.vkey) hash_varchar_keys(st);
             Side&          bs = st.bs();
             Side&          ps = st.ps();
             const uint32_t bits = join_bits(js, bs.rel->n);
@@ -772,6 +785,8 @@ class Exec {
             cap = nrows;  // exact size, run the probe again
         }
 
+        if (st.vkey && nrows) nrows = verify_varchar_pairs(st, nrows);
+
         // ------------------------------------------------ assemble the outputs
         Rel out;
         out.n = nrows;
@@ -859,6 +874,94 @@ class Exec {
         return out;
     }
 
+    // The VARCHAR pages of a base column + their row directory in HBM (uploaded once per table).
+    struct VcDev {
+        const uint8_t*  pages;
+        uint32_t        n_pages;
+        const uint32_t* dir;
+    };
+    VcDev ensure_vc_dev(int vc_table, int vc_col) {
+        if (vc_table < 0 || (uint64_t)vc_table >= n_tables) throw_fmt(RJ_ERR_ARG, "VARCHAR column without provenance");
+        const Table*       t = table_by_id((uint64_t)vc_table);
+        const TableColumn& tc = t->cols[vc_col];
+        if (tc.vc_pages.size() > 0xfffffff0ull || t->num_rows > 0xfffffff0ull)
+            throw_fmt(RJ_ERR_UNSUPPORTED, "VARCHAR column too large for the device path");
+        auto key = std::make_pair(vc_table, vc_col);
+        auto it = vc_dir_.find(key);
+        if (it == vc_dir_.end()) {
+            it = vc_dir_.emplace(key, std::vector<uint64_t>()).first;
+            varchar_dir_build(tc.vc_pages.data(), tc.vc_pages.size(), t->num_rows, it->second);
+        }
+        const uint32_t npg = (uint32_t)tc.vc_pages.size();
+        if (!tc.vc_dev) {
+            tc.vc_dev = ctx->buf(std::max<uint64_t>(npg, 1) * PAGE_BYTES);
+            upload_host_pages(ctx, tc.vc_pages.data(), npg, tc.vc_dev->as<uint8_t>());
+            std::vector<uint32_t> dir32(it->second.begin(), it->second.end());
+            tc.vc_dev_dir = ctx->buf(dir32.size() * 4);
+            RJ_HIP(hipMemcpyAsync(tc.vc_dev_dir->p, dir32.data(), dir32.size() * 4, hipMemcpyHostToDevice,
+                                  ctx->stream));
+            ctx->sync();  // dir32 is a local
+        }
+        return VcDev{tc.vc_dev->as<uint8_t>(), npg, tc.vc_dev_dir->as<uint32_t>()};
+    }
+
+    // VARCHAR join keys: hash both key columns, join on the hashes (see JoinState::VKey)
+    void hash_varchar_keys(JoinState& st) {
+        int k = 0;
+        for (Side* s : {&st.ls, &st.rs}) {
+            JoinState::VKey& v = st.vk[k++];
+            const DCol       kc = s->rel->cols[s->key_col];  // a row-id column of its base table
+            if (kc.kind != COL_IOTA && kc.kind != COL_DENSE) throw_fmt(RJ_ERR_ARG, "VARCHAR key column of unknown shape");
+            const VcDev d = ensure_vc_dev(kc.vc_table, kc.vc_col);
+            const uint32_t n = (uint32_t)s->rel->n;
+            v.pages = d.pages;
+            v.n_pages = d.n_pages;
+            v.rows = ctx->buf(std::max<uint64_t>(n, 1) * sizeof(VcRow));
+            v.hash = ctx->buf(std::max<uint64_t>(n, 1) * 8);
+            v.valid = ctx->buf(std::max<uint64_t>(n, 1));
+            launch_vc_hash(L, d.pages, d.n_pages, d.dir,
+                           kc.kind == COL_DENSE ? reinterpret_cast<const uint32_t*>(kc.ptr) : nullptr, n,
+                           v.rows->as<VcRow>(), v.hash->as<uint64_t>(), v.valid->as<uint8_t>(),
+                           ctx->tune.vkey_hash_bits > 0 && ctx->tune.vkey_hash_bits < 64
+                               ? ((1ull << ctx->tune.vkey_hash_bits) - 1ull)
+                               : ~0ull);
+            v.rel = *s->rel;
+            DCol h;
+            h.type = RJ_INT64;
+            h.kind = COL_DENSE;
+            h.width = 8;
+            h.ptr = v.hash->as<uint8_t>();
+            h.valid = v.valid->as<uint8_t>();
+            v.rel.cols.push_back(h);
+            s->rel = &v.rel;
+            s->key_col = v.rel.cols.size() - 1;
+        }
+    }
+
+    // Every joined pair is compared byte for byte; the (build row, probe row) streams are
+    // compacted if — and only if — a hash collision let a pair of different strings through.
+    uint64_t verify_varchar_pairs(JoinState& st, uint64_t nrows) {
+        Side &                 bs = st.bs(), &ps = st.ps();
+        const JoinState::VKey& vb = st.vk[st.build_left ? 0 : 1];
+        const JoinState::VKey& vp = st.vk[st.build_left ? 1 : 0];
+        const uint32_t         n = (uint32_t)nrows;
+        BufP                   keep = ctx->buf(n), bad = ctx->buf(16);
+        RJ_HIP(hipMemsetAsync(bad->p, 0, 16, ctx->stream));
+        launch_vc_verify(L, vb.pages, vb.n_pages, vb.rows->as<VcRow>(), vp.pages, vp.n_pages, vp.rows->as<VcRow>(),
+                         bs.stream->as<uint32_t>(), ps.stream->as<uint32_t>(), n, keep->as<uint8_t>(),
+                         bad->as<unsigned long long>());
+        unsigned long long n_bad = 0;
+        RJ_HIP(hipMemcpyAsync(&n_bad, bad->p, 8, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->sync();
+        if (n_bad == 0) return nrows;
+        BufP nb = ctx->buf(std::max<uint64_t>(nrows - n_bad, 1) * 4), np = ctx->buf(std::max<uint64_t>(nrows - n_bad, 1) * 4);
+        launch_vc_compact(L, keep->as<uint8_t>(), bs.stream->as<uint32_t>(), ps.stream->as<uint32_t>(), n,
+                          nb->as<uint32_t>(), np->as<uint32_t>(), bad->as<unsigned long long>() + 1);
+        bs.stream = nb;
+        ps.stream = np;
+        return nrows - n_bad;
+    }
+
     void launch_heavy_tasks_zeroed(const Parted& PB, const Parted& PP, const BufP& tasks,
                                    const BufP& counters, uint32_t max_tasks) {
         RJ_HIP(hipMemsetAsync(counters->p, 0, 16, ctx->stream));
@@ -879,27 +982,13 @@ class Exec {
         if (ctx->tune.varchar_dev_rows > 0 && n >= (uint64_t)ctx->tune.varchar_dev_rows &&
             tc.vc_pages.size() <= 0xfffffff0ull && t->num_rows <= 0xfffffff0ull) {
             // ---- large result: gather + encode on the device (rj_varchar_dev.hip)
-            auto it = vc_dir_.find(key);
-            if (it == vc_dir_.end()) {
-                it = vc_dir_.emplace(key, std::vector<uint64_t>()).first;
-                varchar_dir_build(tc.vc_pages.data(), tc.vc_pages.size(), t->num_rows, it->second);
-            }
-            const uint32_t npg = (uint32_t)tc.vc_pages.size();
-            if (!tc.vc_dev) {  // the base column's pages + row directory go to HBM once per table
-                tc.vc_dev = ctx->buf(std::max<uint64_t>(npg, 1) * PAGE_BYTES);
-                upload_host_pages(ctx, tc.vc_pages.data(), npg, tc.vc_dev->as<uint8_t>());
-                std::vector<uint32_t> dir32(it->second.begin(), it->second.end());
-                tc.vc_dev_dir = ctx->buf(dir32.size() * 4);
-                RJ_HIP(hipMemcpyAsync(tc.vc_dev_dir->p, dir32.data(), dir32.size() * 4, hipMemcpyHostToDevice,
-                                      ctx->stream));
-                ctx->sync();  // dir32 is a local
-            }
+            const VcDev    vd = ensure_vc_dev(src.vc_table, src.vc_col);
+            const uint32_t npg = vd.n_pages;
             auto           tv1 = std::chrono::steady_clock::now();
             const uint32_t nr = (uint32_t)n, chunks = (nr + VC_CHUNK - 1) / VC_CHUNK;
             BufP           vrows = ctx->buf((uint64_t)nr * sizeof(VcRow));
             BufP           pcnt = ctx->buf((uint64_t)chunks * 4), pbase = ctx->buf(((uint64_t)chunks + 1) * 4);
-            launch_vc_resolve(L, tc.vc_dev->as<uint8_t>(), npg, tc.vc_dev_dir->as<uint32_t>(), dev_rowids, nr,
-                              vrows->as<VcRow>());
+            launch_vc_resolve(L, vd.pages, npg, vd.dir, dev_rowids, nr, vrows->as<VcRow>());
             launch_vc_walk(L, vrows->as<VcRow>(), nr, pcnt->as<uint32_t>(), nullptr, nullptr);
             launch_scan_bins(L, pcnt->as<uint32_t>(), chunks, pbase->as<uint32_t>(), nullptr);
             uint32_t n_out = 0;
@@ -909,7 +998,7 @@ class Exec {
             rc.dev_pages = ctx->buf(std::max<uint64_t>(n_out, 1) * PAGE_BYTES);
             launch_vc_walk(L, vrows->as<VcRow>(), nr, pcnt->as<uint32_t>(), pbase->as<uint32_t>(),
                            plist->as<VcPage>());
-            launch_vc_encode(L, tc.vc_dev->as<uint8_t>(), npg, vrows->as<VcRow>(), plist->as<VcPage>(), n_out,
+            launch_vc_encode(L, vd.pages, npg, vrows->as<VcRow>(), plist->as<VcPage>(), n_out,
                              rc.dev_pages->as<uint8_t>());
             rc.n_pages = n_out;
             if (diag) {

@@ -178,6 +178,8 @@ struct Tuning {
     int diag = 0;         // RJ_DIAG: 1 = join phase stamps, 2 = host-side timings on stderr
     int varchar_dev_rows = 200000;  // RJ_TUNE_VARCHAR_DEV: root VARCHAR columns of at least this many
                                     // rows are gathered + encoded on the device (0 = never)
+    int vkey_hash_bits = 0;  // RJ_DEBUG_VKEY_HASH_BITS: keep only this many bits of a VARCHAR key's hash
+                             // (tests: forces collisions through the verify + compact path)
     int sync_upload = 0;  // RJ_SYNC_UPLOAD: upload every input before the plan starts
     void from_env();
 };

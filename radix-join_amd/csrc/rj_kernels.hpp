@@ -108,6 +108,16 @@ void launch_encode_nullable(const Launch& L, const uint8_t* values, const uint8_
 //      of Table::to_columnar, reference src/build_table.cpp:595-677)
 void launch_vc_resolve(const Launch& L, const uint8_t* pages, uint32_t n_pages, const uint32_t* row_base,
                        const uint32_t* rowids, uint32_t n, VcRow* out);
+// VARCHAR join keys: 64-bit FNV-1a of every row's string (+ where it sits, + validity), the
+// byte-for-byte check of the joined pairs, and the compaction that only a hash collision triggers
+void launch_vc_hash(const Launch& L, const uint8_t* pages, uint32_t n_pages, const uint32_t* row_base,
+                    const uint32_t* rowids, uint32_t n, VcRow* rows, uint64_t* hash, uint8_t* valid,
+                    uint64_t hash_mask = ~0ull);
+void launch_vc_verify(const Launch& L, const uint8_t* pages_b, uint32_t np_b, const VcRow* rows_b,
+                      const uint8_t* pages_p, uint32_t np_p, const VcRow* rows_p, const uint32_t* bidx,
+                      const uint32_t* pidx, uint32_t n, uint8_t* keep, unsigned long long* n_bad);
+void launch_vc_compact(const Launch& L, const uint8_t* keep, const uint32_t* bidx, const uint32_t* pidx, uint32_t n,
+                       uint32_t* out_b, uint32_t* out_p, unsigned long long* cursor);
 // page_out == nullptr: pages_in_chunk[c] = pages of chunk c; else the pages are written to
 // page_out[page_base[c] ...]
 void launch_vc_walk(const Launch& L, const VcRow* rows, uint32_t n, uint32_t* pages_in_chunk,

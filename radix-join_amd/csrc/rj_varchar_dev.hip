@@ -43,44 +43,135 @@ __device__ __forceinline__ uint32_t popcount_below(const uint8_t* bitmap, uint32
 
 }  // namespace
 
+// row id -> where its string sits
+__device__ __forceinline__ VcRow vc_resolve_row(const uint8_t* pages, uint32_t n_pages, const uint32_t* row_base,
+                                                uint32_t row) {
+    VcRow r{0, 0, VC_NULL};
+    if (row >= row_base[n_pages]) return r;  // rows the pages do not cover are NULL
+    // largest pg with row_base[pg] <= row (pages holding no row, 0xfffe, share their
+    // successor's base: the search lands behind them)
+    uint32_t lo = 0, hi = n_pages;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (row_base[mid] <= row)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const uint8_t* page = pages + (size_t)lo * PAGE_BYTES;
+    const uint32_t nr = rd16(page);
+    if (nr == 0xffffu) {  // long string: this page + the 0xfffe pages behind it
+        uint32_t total = rd16(page + 2);
+        for (uint32_t q = lo + 1; q < n_pages && rd16(pages + (size_t)q * PAGE_BYTES) == 0xfffeu; ++q)
+            total += rd16(pages + (size_t)q * PAGE_BYTES + 2);
+        return VcRow{lo, VC_LONG, total};
+    }
+    const uint32_t at = row - row_base[lo];
+    const uint8_t* bitmap = page + PAGE_BYTES - (nr + 7) / 8;
+    if ((bitmap[at >> 3] >> (at & 7u)) & 1u) {
+        const uint32_t idx = popcount_below(bitmap, at);  // index among the non-NULL values
+        const uint32_t nnn = rd16(page + 2);
+        const uint32_t end = rd16(page + 4 + (size_t)idx * 2);
+        const uint32_t beg = idx ? rd16(page + 4 + (size_t)(idx - 1) * 2) : 0u;
+        r = VcRow{lo, 4u + nnn * 2u + beg, end - beg};
+    }
+    return r;
+}
+
 __global__ __launch_bounds__(256) void k_vc_resolve(const uint8_t* pages, uint32_t n_pages,
                                                     const uint32_t* row_base, const uint32_t* rowids,
                                                     uint32_t n, VcRow* out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t row = rowids[i];
-    VcRow          r{0, 0, VC_NULL};
-    if (row < row_base[n_pages]) {  // rows the pages do not cover are NULL
-        // largest pg with row_base[pg] <= row (pages holding no row, 0xfffe, share their
-        // successor's base: the search lands behind them)
-        uint32_t lo = 0, hi = n_pages;
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (row_base[mid] <= row)
-                lo = mid;
-            else
-                hi = mid;
-        }
-        const uint8_t* page = pages + (size_t)lo * PAGE_BYTES;
-        const uint32_t nr = rd16(page);
-        if (nr == 0xffffu) {  // long string: this page + the 0xfffe pages behind it
-            uint32_t total = rd16(page + 2);
-            for (uint32_t q = lo + 1; q < n_pages && rd16(pages + (size_t)q * PAGE_BYTES) == 0xfffeu; ++q)
-                total += rd16(pages + (size_t)q * PAGE_BYTES + 2);
-            r = VcRow{lo, VC_LONG, total};
+    out[i] = vc_resolve_row(pages, n_pages, row_base, rowids[i]);
+}
+
+// Byte `pos` of a resolved string (long strings: walk the page chain — rare, slow, correct).
+__device__ __forceinline__ uint32_t vc_byte(const uint8_t* pages, uint32_t n_pages, const VcRow& r, uint32_t pos) {
+    if (r.beg != VC_LONG) return pages[(size_t)r.page * PAGE_BYTES + r.beg + pos];
+    uint32_t q = r.page;
+    while (q < n_pages) {
+        const uint8_t* page = pages + (size_t)q * PAGE_BYTES;
+        const uint32_t nc = rd16(page + 2);
+        if (pos < nc) return page[4 + pos];
+        pos -= nc;
+        ++q;
+    }
+    return 0;
+}
+
+// ---- VARCHAR join keys (reference hash_join_omp<std::string>, src/execute.cpp:33-38,278):
+// the strings of a key column are hashed to 64 bits (FNV-1a, as the reference does) and joined as
+// 64-bit keys; every matching pair is then compared byte for byte (k_vc_verify), so hash
+// collisions cannot add rows.  rows[i] keeps where row i's string sits for that comparison.
+__global__ __launch_bounds__(256) void k_vc_hash(const uint8_t* pages, uint32_t n_pages, const uint32_t* row_base,
+                                                 const uint32_t* rowids /* nullptr: row i itself */, uint32_t n,
+                                                 VcRow* rows, uint64_t* hash, uint8_t* valid, uint64_t hash_mask) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const VcRow r = vc_resolve_row(pages, n_pages, row_base, rowids ? rowids[i] : i);
+    rows[i] = r;
+    uint64_t h = 0xcbf29ce484222325ull;
+    if (r.len != VC_NULL) {
+        if (r.beg != VC_LONG) {
+            const uint8_t* s = pages + (size_t)r.page * PAGE_BYTES + r.beg;
+            for (uint32_t k = 0; k < r.len; ++k) h = (h ^ s[k]) * 0x100000001b3ull;
         } else {
-            const uint32_t at = row - row_base[lo];
-            const uint8_t* bitmap = page + PAGE_BYTES - (nr + 7) / 8;
-            if ((bitmap[at >> 3] >> (at & 7u)) & 1u) {
-                const uint32_t idx = popcount_below(bitmap, at);  // index among the non-NULL values
-                const uint32_t nnn = rd16(page + 2);
-                const uint32_t end = rd16(page + 4 + (size_t)idx * 2);
-                const uint32_t beg = idx ? rd16(page + 4 + (size_t)(idx - 1) * 2) : 0u;
-                r = VcRow{lo, 4u + nnn * 2u + beg, end - beg};
+            uint32_t q = r.page, left = r.len;
+            while (left && q < n_pages) {
+                const uint8_t* page = pages + (size_t)q * PAGE_BYTES;
+                const uint32_t nc = min(left, rd16(page + 2));
+                for (uint32_t k = 0; k < nc; ++k) h = (h ^ page[4 + k]) * 0x100000001b3ull;
+                left -= nc;
+                ++q;
             }
         }
     }
-    out[i] = r;
+    hash[i] = h & hash_mask;  // (all ones; tests narrow it to force collisions)
+    valid[i] = r.len != VC_NULL;
+}
+
+// keep[i] = the build and the probe string of output pair i are equal; *n_bad counts the others
+__global__ __launch_bounds__(256) void k_vc_verify(const uint8_t* pages_b, uint32_t np_b, const VcRow* rows_b,
+                                                   const uint8_t* pages_p, uint32_t np_p, const VcRow* rows_p,
+                                                   const uint32_t* bidx, const uint32_t* pidx, uint32_t n,
+                                                   uint8_t* keep, unsigned long long* n_bad) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const VcRow a = rows_b[bidx[i]], b = rows_p[pidx[i]];
+    bool        eq = a.len == b.len && a.len != VC_NULL;
+    if (eq) {
+        if (a.beg != VC_LONG && b.beg != VC_LONG) {
+            const uint8_t* x = pages_b + (size_t)a.page * PAGE_BYTES + a.beg;
+            const uint8_t* y = pages_p + (size_t)b.page * PAGE_BYTES + b.beg;
+            for (uint32_t k = 0; k < a.len && eq; ++k) eq = x[k] == y[k];
+        } else {
+            for (uint32_t k = 0; k < a.len && eq; ++k)
+                eq = vc_byte(pages_b, np_b, a, k) == vc_byte(pages_p, np_p, b, k);
+        }
+    }
+    keep[i] = eq;
+    if (!eq) atomicAdd(n_bad, 1ull);
+}
+
+// order-free compaction of the surviving pairs (only runs when a hash collision was found)
+__global__ __launch_bounds__(256) void k_vc_compact(const uint8_t* keep, const uint32_t* bidx, const uint32_t* pidx,
+                                                    uint32_t n, uint32_t* out_b, uint32_t* out_p,
+                                                    unsigned long long* cursor) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool     k = i < n && keep[i];
+    const uint64_t mask = __ballot(k);
+    if (mask == 0) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(cursor, (unsigned long long)__popcll(mask));
+    base = __shfl(base, 0);
+    if (k) {
+        const uint32_t o = (uint32_t)base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        out_b[o] = bidx[i];
+        out_p[o] = pidx[i];
+    }
 }
 
 // The page-fill rule, one lane per chunk.  WRITE = false: count the chunk's pages.
@@ -266,6 +357,28 @@ void launch_vc_resolve(const Launch& L, const uint8_t* pages, uint32_t n_pages, 
                        const uint32_t* rowids, uint32_t n, VcRow* out) {
     if (!n) return;
     RJ_VLAUNCH(L, "varchar_resolve", k_vc_resolve, (n + 255) / 256, 256, pages, n_pages, row_base, rowids, n, out);
+}
+
+void launch_vc_hash(const Launch& L, const uint8_t* pages, uint32_t n_pages, const uint32_t* row_base,
+                    const uint32_t* rowids, uint32_t n, VcRow* rows, uint64_t* hash, uint8_t* valid,
+                    uint64_t hash_mask) {
+    if (!n) return;
+    RJ_VLAUNCH(L, "varchar_hash", k_vc_hash, (n + 255) / 256, 256, pages, n_pages, row_base, rowids, n, rows, hash, valid,
+               hash_mask);
+}
+
+void launch_vc_verify(const Launch& L, const uint8_t* pages_b, uint32_t np_b, const VcRow* rows_b,
+                      const uint8_t* pages_p, uint32_t np_p, const VcRow* rows_p, const uint32_t* bidx,
+                      const uint32_t* pidx, uint32_t n, uint8_t* keep, unsigned long long* n_bad) {
+    if (!n) return;
+    RJ_VLAUNCH(L, "varchar_verify", k_vc_verify, (n + 255) / 256, 256, pages_b, np_b, rows_b, pages_p, np_p, rows_p,
+               bidx, pidx, n, keep, n_bad);
+}
+
+void launch_vc_compact(const Launch& L, const uint8_t* keep, const uint32_t* bidx, const uint32_t* pidx, uint32_t n,
+                       uint32_t* out_b, uint32_t* out_p, unsigned long long* cursor) {
+    if (!n) return;
+    RJ_VLAUNCH(L, "varchar_compact", k_vc_compact, (n + 255) / 256, 256, keep, bidx, pidx, n, out_b, out_p, cursor);
 }
 
 void launch_vc_walk(const Launch& L, const VcRow* rows, uint32_t n, uint32_t* pages_in_chunk,
