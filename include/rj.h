@@ -46,8 +46,8 @@ typedef enum rj_status {
     RJ_ERR_NOMEM     = 3, /* device or host allocation failed                 */
     RJ_ERR_DATA      = 4, /* pages inconsistent with num_rows ("row_idx",
                              reference build_table.cpp:334-336)               */
-    RJ_ERR_UNSUPPORTED = 5, /* e.g. VARCHAR join key (never occurs in JOB,
-                             reference ANNOUNCEMENTS.md:11)                   */
+    RJ_ERR_UNSUPPORTED = 5, /* e.g. more than 2^32 rows in one relation, a plan
+                             rj_execute_sharded cannot shard                  */
     RJ_ERR_NO_GPU    = 6  /* no usable HIP device: the product path has no
                              CPU fallback and fails loudly                    */
 } rj_status;

@@ -66,9 +66,10 @@ def random_table(rng, key_type, key_domain, wide):
     return t, types
 
 
-def random_plan(seed):
+def random_plan(seed, keyable=KEYABLE, key_p=(0.6, 0.25, 0.15)):
     rng = np.random.default_rng(seed)
-    key_type = int(rng.choice(KEYABLE, p=[0.6, 0.25, 0.15]))
+    KEYABLE = keyable  # noqa: N806 (shadows the module default inside this plan)
+    key_type = int(rng.choice(KEYABLE, p=list(key_p)))
     n_tables = int(rng.integers(2, 6))
     key_domain = int(rng.choice([300, 1500]))  # shared by the plan's tables so joins do match
     wide = bool(rng.random() < 0.3)
@@ -139,6 +140,37 @@ def test_random_plan_forced_radix(seed, bits):
     if want.num_rows > 400_000:
         pytest.skip("result too large to sort in a unit test")
     c = capi.Context(radix_bits=bits)
+    try:
+        got = capi.execute(p, c)
+    finally:
+        c.destroy()
+    assert got.num_rows == want.num_rows
+    assert pl.canonical_rows(got) == pl.canonical_rows(want)
+
+
+# VARCHAR join keys (reference hash_join_omp<std::string>) in the mix: the same generator with
+# VARCHAR as the plan's key type most of the time; own seed range so that the plans above stay
+# what they were.  Also under a forced multi-pass radix plan (the 64-bit string hashes then go
+# through the partitioner instead of the broadcast join).
+@pytest.mark.parametrize("seed", range(50_000, 50_060))
+def test_random_plan_with_varchar_keys(ctx, seed):
+    p = random_plan(seed, keyable=KEYABLE + (pl.VARCHAR,), key_p=(0.15, 0.1, 0.05, 0.7))
+    want = _oracle.execute(p)
+    if want.num_rows > 400_000:
+        pytest.skip("result too large to sort in a unit test")
+    got = capi.execute(p, ctx)
+    assert got.num_rows == want.num_rows
+    assert [c.type for c in got.columns] == [c.type for c in want.columns]
+    assert pl.canonical_rows(got) == pl.canonical_rows(want)
+
+
+@pytest.mark.parametrize("seed", range(50_000, 50_020))
+def test_random_plan_with_varchar_keys_forced_radix(seed):
+    p = random_plan(seed, keyable=KEYABLE + (pl.VARCHAR,), key_p=(0.15, 0.1, 0.05, 0.7))
+    want = _oracle.execute(p)
+    if want.num_rows > 400_000:
+        pytest.skip("result too large to sort in a unit test")
+    c = capi.Context(radix_bits=11)
     try:
         got = capi.execute(p, c)
     finally:
