@@ -199,6 +199,10 @@ void     rj_result_free(rj_result* r);
  * side (the BASELINE shape); others return RJ_ERR_UNSUPPORTED.                              */
 int rj_execute_sharded(rj_context* ctx, const rj_plan* plan, rj_table* const* tables,
                        uint64_t n_inputs, int32_t flags, rj_result** out /* [n local devices] */);
+/* 1 if rj_execute_sharded (and rj_execute on a multi-device context) can shard this plan, else 0
+ * with the reason in `why` (optional, NUL-terminated, at most why_cap bytes).  Looks at the plan
+ * only: needs neither a context nor a GPU.                                                    */
+int rj_plan_shardable(const rj_plan* plan, char* why, size_t why_cap);
 
 /* Lower-level pieces of the same path, for callers that run the exchange themselves (e.g.
  * torch.distributed in pyrj.dist, gloo on CPU in the tests).  Tuples are SoA: `key` (int32)

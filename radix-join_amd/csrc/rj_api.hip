@@ -291,6 +291,21 @@ int rj_execute_sharded(rj_context* ctx, const rj_plan* plan, rj_table* const* ta
     });
 }
 
+int rj_plan_shardable(const rj_plan* plan, char* why, size_t why_cap) {
+    std::string w;
+    bool        ok = false;
+    try {
+        ok = plan_shardable(plan, &w);
+    } catch (const std::exception& e) {
+        w = e.what();
+    }
+    if (why && why_cap) {
+        strncpy(why, ok ? "" : (w.empty() ? "malformed plan" : w.c_str()), why_cap - 1);
+        why[why_cap - 1] = 0;
+    }
+    return ok ? 1 : 0;
+}
+
 int rj_shard_partition(rj_context* ctx, const rj_table* t, uint64_t key_col, uint64_t carry_col,
                        uint32_t n_ranks, rj_tuples* out, uint64_t* counts) {
     if (!ctx || !t || !out || !counts) return RJ_ERR_ARG;

@@ -81,6 +81,7 @@ EXPORTS = [
     "rj_context_device",
     "rj_comm_id_create",
     "rj_execute_sharded",
+    "rj_plan_shardable",
     "rj_table_upload",
     "rj_table_adopt_device",
     "rj_table_release",
@@ -178,6 +179,8 @@ def load():
     L.rj_comm_id_create.restype = C.c_int
     L.rj_execute_sharded.argtypes = [vp, C.POINTER(pl.rj_plan), C.POINTER(vp), u64, i32, C.POINTER(vp)]
     L.rj_execute_sharded.restype = C.c_int
+    L.rj_plan_shardable.argtypes = [C.POINTER(pl.rj_plan), C.c_char_p, C.c_size_t]
+    L.rj_plan_shardable.restype = C.c_int
     L.rj_table_upload.argtypes = [vp, C.POINTER(pl.rj_input), C.POINTER(vp)]
     L.rj_table_upload.restype = C.c_int
     L.rj_table_adopt_device.argtypes = [vp, u64, u64, C.POINTER(i32), C.POINTER(vp), C.POINTER(u64), C.POINTER(vp)]
@@ -446,6 +449,16 @@ class Context:
             "lds_per_cu": int(d.lds_per_cu),
             "device_count": int(d.device_count),
         }
+
+
+def plan_shardable(plan: pl.Plan):
+    """rj_plan_shardable -> (bool, reason).  Needs no GPU."""
+    L = load()
+    cplan, keep = pl.plan_to_c(plan, with_inputs=False)
+    buf = C.create_string_buffer(256)
+    ok = L.rj_plan_shardable(C.byref(cplan), buf, 256)
+    del keep
+    return bool(ok), buf.value.decode()
 
 
 def make_comm_id() -> bytes:

@@ -63,3 +63,34 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h", "Makefile")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "rjo_" not in txt and "librjo" not in txt and "_oracle" not in txt, f
+
+
+def test_plan_shardable_is_decided_from_the_plan_alone():
+    """rj_plan_shardable needs neither a context nor a GPU: every JoinNode may carry at most one
+    fixed-width non-key column per side, and no scan may output VARCHAR"""
+    from pyrj import capi
+    from pyrj import plan as pl
+
+    def plan(b_out, p_out, j_out):
+        p = pl.Plan()
+        p.new_scan_node(0, b_out)
+        p.new_scan_node(1, p_out)
+        p.new_join_node(True, 0, 1, 0, 0, j_out)
+        p.root = 2
+        return p
+
+    i32, i64, vc = pl.INT32, pl.INT64, pl.VARCHAR
+    ok, why = capi.plan_shardable(plan([(0, i32), (1, i64)], [(0, i32), (1, i32)], [(0, i32), (1, i64), (3, i32)]))
+    assert ok and why == ""
+    ok, why = capi.plan_shardable(plan([(0, i32), (1, i64), (2, i32)], [(0, i32)], [(1, i64), (2, i32)]))
+    assert not ok and "more than one non-key column" in why
+    ok, why = capi.plan_shardable(plan([(0, i32), (1, vc)], [(0, i32)], [(1, vc)]))
+    assert not ok and "VARCHAR" in why
+    # two joins, each within the limit
+    p = pl.Plan()
+    a = p.new_scan_node(0, [(0, i32), (1, i32)])
+    b = p.new_scan_node(1, [(0, i32)])
+    j1 = p.new_join_node(True, a, b, 0, 0, [(0, i32), (1, i32)])
+    c = p.new_scan_node(2, [(0, i32), (1, i64)])
+    p.root = p.new_join_node(False, j1, c, 1, 0, [(0, i32), (3, i64), (1, i32)])
+    assert capi.plan_shardable(p)[0]
