@@ -176,7 +176,7 @@ void Comm::allgather_u64(const std::vector<std::vector<uint64_t>>& vals, size_t 
     RJ_HIP(hipSetDevice(lanes_[0]->device));
 }
 
-void Comm::all_to_all(const std::vector<XferSpec>& specs, const std::vector<hipEvent_t>& ready,
+void Comm::all_to_all(const std::vector<std::vector<XferSpec>>& specs, const std::vector<hipEvent_t>& ready,
                       std::vector<hipEvent_t>& done) {
     const int nl = n_local();
     if (mode_ == P2P) {
@@ -188,19 +188,21 @@ void Comm::all_to_all(const std::vector<XferSpec>& specs, const std::vector<hipE
         }
         for (int s = 0; s < nl; ++s) {
             RJ_HIP(hipSetDevice(lanes_[s]->device));
-            const XferSpec& S = specs[s];
-            for (int d = 0; d < nl; ++d) {
-                const uint64_t n = S.send_cnt[rank_base_ + d];
-                if (!n) continue;
-                const XferSpec& D = specs[d];
-                if (D.recv_cnt[rank_base_ + s] != n)
-                    throw_fmt(RJ_ERR_DEVICE, "exchange counts disagree (%d -> %d)", s, d);
-                uint8_t*       dst = D.recv + D.recv_off[rank_base_ + s];
-                const uint8_t* src = S.send + S.send_off[rank_base_ + d];
-                if (lanes_[s]->device == lanes_[d]->device)
-                    RJ_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, xfer_[s]));
-                else
-                    RJ_HIP(hipMemcpyPeerAsync(dst, lanes_[d]->device, src, lanes_[s]->device, n, xfer_[s]));
+            for (size_t a = 0; a < specs[s].size(); ++a) {
+                const XferSpec& S = specs[s][a];
+                for (int d = 0; d < nl; ++d) {
+                    const uint64_t n = S.send_cnt[rank_base_ + d];
+                    if (!n) continue;
+                    const XferSpec& D = specs[d][a];
+                    if (D.recv_cnt[rank_base_ + s] != n)
+                        throw_fmt(RJ_ERR_DEVICE, "exchange counts disagree (%d -> %d)", s, d);
+                    uint8_t*       dst = D.recv + D.recv_off[rank_base_ + s];
+                    const uint8_t* src = S.send + S.send_off[rank_base_ + d];
+                    if (lanes_[s]->device == lanes_[d]->device)
+                        RJ_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, xfer_[s]));
+                    else
+                        RJ_HIP(hipMemcpyPeerAsync(dst, lanes_[d]->device, src, lanes_[s]->device, n, xfer_[s]));
+                }
             }
             RJ_HIP(hipEventRecord(sent_[s], xfer_[s]));
         }
@@ -215,22 +217,22 @@ void Comm::all_to_all(const std::vector<XferSpec>& specs, const std::vector<hipE
             RJ_HIP(hipSetDevice(lanes_[l]->device));
             RJ_HIP(hipStreamWaitEvent(xfer_[l], ready[l], 0));
         }
+        // slices travel in pieces of at most 1 GiB (both ends cut the same total the same
+        // way): multi-GiB point-to-point operations are outside what RCCL is exercised with
+        constexpr uint64_t PIECE = 1ull << 30;
         RJ_NCCL(R.GroupStart());
         for (int l = 0; l < nl; ++l) {
             RJ_HIP(hipSetDevice(lanes_[l]->device));
-            const XferSpec& X = specs[l];
-            ncclComm_t      c = static_cast<ncclComm_t>(nccl_[l]);
-            // slices travel in pieces of at most 1 GiB (both ends cut the same total the same
-            // way): multi-GiB point-to-point operations are outside what RCCL is exercised with
-            constexpr uint64_t PIECE = 1ull << 30;
-            for (int p = 0; p < world_; ++p) {
-                for (uint64_t o = 0; o < X.send_cnt[p]; o += PIECE)
-                    RJ_NCCL(R.Send(X.send + X.send_off[p] + o, std::min(PIECE, X.send_cnt[p] - o), ncclUint8, p, c,
-                                   xfer_[l]));
-                for (uint64_t o = 0; o < X.recv_cnt[p]; o += PIECE)
-                    RJ_NCCL(R.Recv(X.recv + X.recv_off[p] + o, std::min(PIECE, X.recv_cnt[p] - o), ncclUint8, p, c,
-                                   xfer_[l]));
-            }
+            ncclComm_t c = static_cast<ncclComm_t>(nccl_[l]);
+            for (const XferSpec& X : specs[l])
+                for (int p = 0; p < world_; ++p) {
+                    for (uint64_t o = 0; o < X.send_cnt[p]; o += PIECE)
+                        RJ_NCCL(R.Send(X.send + X.send_off[p] + o, std::min(PIECE, X.send_cnt[p] - o), ncclUint8, p, c,
+                                       xfer_[l]));
+                    for (uint64_t o = 0; o < X.recv_cnt[p]; o += PIECE)
+                        RJ_NCCL(R.Recv(X.recv + X.recv_off[p] + o, std::min(PIECE, X.recv_cnt[p] - o), ncclUint8, p, c,
+                                       xfer_[l]));
+                }
         }
         RJ_NCCL(R.GroupEnd());
         for (int l = 0; l < nl; ++l) {

@@ -48,11 +48,13 @@ class Comm {
     void allgather_u64(const std::vector<std::vector<uint64_t>>& vals, size_t k,
                        std::vector<std::vector<uint64_t>>& all);
 
-    // One all-to-all: specs[l] = local rank l's slices.  Enqueued on the exchange streams, which
-    // first wait for `ready[l]` (recorded on lane l's compute stream once its send buffer is
-    // complete).  On return done[l] has been recorded: lane l's recv buffer is complete when it
-    // fires.  Buffers must stay alive until then.
-    void all_to_all(const std::vector<XferSpec>& specs, const std::vector<hipEvent_t>& ready,
+    // One all-to-all of a relation: specs[l] = local rank l's slices, one XferSpec per array of
+    // the tuple layout (one for packed pairs, two for key array + carry-pair array); all arrays
+    // travel in ONE group.  Enqueued on the exchange streams, which first wait for `ready[l]`
+    // (recorded on lane l's compute stream once its send buffers are complete).  On return
+    // done[l] has been recorded: lane l's recv buffers are complete when it fires.  Buffers must
+    // stay alive until then.
+    void all_to_all(const std::vector<std::vector<XferSpec>>& specs, const std::vector<hipEvent_t>& ready,
                     std::vector<hipEvent_t>& done);
 
     hipStream_t xfer_stream(int lane) const { return xfer_[lane]; }

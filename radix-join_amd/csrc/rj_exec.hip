@@ -1277,15 +1277,16 @@ class ShardedExec {
                     X.ws.w.w[a] = X.recv[a]->as<uint32_t>();
                 }
             }
-            for (int a = 0; a < n_arrays; ++a) {
-                const uint32_t wbytes = array_width(XS[0].A, KW, CW, a);
-                if (!wbytes) continue;
-                std::vector<XferSpec>   specs((size_t)nl_);
-                std::vector<hipEvent_t> ready, done;
-                for (int l = 0; l < nl_; ++l) {
-                    const int me = rank_base_ + l;
-                    XferSpec& sp = specs[l];
-                    SideX&    X = XS[l];
+            // one all-to-all per relation: every array of the layout travels in the same group
+            std::vector<std::vector<XferSpec>> specs((size_t)nl_);
+            std::vector<hipEvent_t>            ready, done;
+            for (int l = 0; l < nl_; ++l) {
+                const int me = rank_base_ + l;
+                SideX&    X = XS[l];
+                for (int a = 0; a < n_arrays; ++a) {
+                    const uint32_t wbytes = array_width(X.A, KW, CW, a);
+                    if (!wbytes) continue;
+                    XferSpec sp;
                     sp.send = reinterpret_cast<const uint8_t*>(X.A.w.w[a]);
                     sp.recv = reinterpret_cast<uint8_t*>(X.ws.w.w[a]);
                     sp.send_off.assign((size_t)world_, 0);
@@ -1301,19 +1302,18 @@ class ShardedExec {
                         sp.recv_cnt[r] = c * wbytes;
                         roff += c;
                     }
-                    ready.push_back(X.ready.e);
-                    done.push_back(X.done.e);
+                    specs[l].push_back(std::move(sp));
                 }
-                // (an exchange stream runs its all-to-alls in order: `done` of the last array
-                // covers the earlier ones)
-                if (comm_) {
-                    comm_->all_to_all(specs, ready, done);
-                } else {  // one rank, no transport: the slice is the whole
-                    use(0);
-                    RJ_HIP(hipMemcpyAsync(specs[0].recv, specs[0].send, specs[0].send_cnt[0],
-                                          hipMemcpyDeviceToDevice, g_->stream));
-                    RJ_HIP(hipEventRecord(done[0], g_->stream));
-                }
+                ready.push_back(X.ready.e);
+                done.push_back(X.done.e);
+            }
+            if (comm_) {
+                comm_->all_to_all(specs, ready, done);
+            } else {  // one rank, no transport: the slice is the whole
+                use(0);
+                for (const XferSpec& sp : specs[0])
+                    RJ_HIP(hipMemcpyAsync(sp.recv, sp.send, sp.send_cnt[0], hipMemcpyDeviceToDevice, g_->stream));
+                RJ_HIP(hipEventRecord(done[0], g_->stream));
             }
         }
 
