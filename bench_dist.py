@@ -69,6 +69,13 @@ def verify_sharded(res, rel, device):
 
 
 def main(args, rank, world, dev_index, device):
+    # RCCL prints a version banner on stdout when a communicator comes up; stdout is reserved for
+    # the ONE JSON line, so everything else of this run goes to stderr at the descriptor level
+    import sys
+
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("nccl", device_id=device)
     name = args.workload
@@ -156,7 +163,10 @@ def main(args, rank, world, dev_index, device):
             # rank 0's kernels on its 1/N share (the exchange itself is not a kernel of ours)
             "roofline": bench.roofline(stats, rel.n, rel.n, args.steps, 8 if rel.payload64 else 4, f"{name}_x{world}") if stats else None,
         }
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     R.release()
     S.release()
     ctx.destroy()
