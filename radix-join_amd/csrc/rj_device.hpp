@@ -70,6 +70,7 @@ constexpr int PT_THREADS = RJ_PT_THREADS;         // waves = PT_THREADS / 64
 constexpr int PT_ITEMS   = RJ_PT_ITEMS;           // tuples per thread per tile
 constexpr int PT_TILE    = PT_THREADS * PT_ITEMS; // 16384 tuples = 64 KiB of LDS staging; longer
                                                   // digit runs per tile = fewer partial HBM lines
+constexpr uint32_t PT_ALL_ITEMS = PT_ITEMS >= 32 ? 0xffffffffu : ((1u << (PT_ITEMS & 31)) - 1u);  // one bit per item
 constexpr int PT_MAXF    = 512;                   // max fan-out per pass (9 bits)
 constexpr int PT_MAXBITS = 9;
 constexpr int PT_FINEBITS = 15;                   // fine (two-digit) histogram: 2^15 bins = 128 KiB of LDS
@@ -80,7 +81,7 @@ static_assert(PT_TILE * 8 + 3 * PT_MAXF * 4 + (PT_THREADS / 64) * 4 <= LDS_BYTES
               "scatter tile does not fit the 160 KiB of LDS");
 static_assert((4 << PT_FINEBITS) <= LDS_BYTES, "fine histogram does not fit the LDS");
 static_assert(PT_TILE <= 65536, "ranks are packed into 16 bits");
-static_assert(PT_ITEMS % 4 == 0, "full tiles are loaded as 16-byte vectors");
+static_assert(PT_ITEMS % 4 == 0 && PT_ITEMS <= 32, "full tiles are loaded as 16-byte vectors; one mask bit per item");
 
 struct PassParams {
     const uint32_t* seg_off;    // [nseg+1] input segments (previous pass' partitions);

@@ -337,7 +337,7 @@ struct DenseLoaderT {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) hk[4 * v + e] = x[e];
             }
-            return (1u << PT_ITEMS) - 1u;
+            return PT_ALL_ITEMS;
         }
         uint32_t ok = 0;
 #pragma unroll
@@ -378,7 +378,7 @@ struct DenseLoaderT {
                     }
                 }
             }
-            return (1u << PT_ITEMS) - 1u;
+            return PT_ALL_ITEMS;
         }
         uint32_t ok = 0;
 #pragma unroll
@@ -426,7 +426,7 @@ struct PackedLoader {
                 hk[2 * v] = x[0];
                 hk[2 * v + 1] = x[2];
             }
-            return (1u << PT_ITEMS) - 1u;
+            return PT_ALL_ITEMS;
         }
         uint32_t ok = 0;
 #pragma unroll
@@ -450,7 +450,7 @@ struct PackedLoader {
                 w[2 * v + 1][0] = x[2];
                 w[2 * v + 1][1] = x[3];
             }
-            return (1u << PT_ITEMS) - 1u;
+            return PT_ALL_ITEMS;
         }
         uint32_t ok = 0;
 #pragma unroll
@@ -539,7 +539,7 @@ struct SrcLoader {
         } else {
             load_col64(s.key, vec, base, end, lo, hi);
         }
-        if (vec) return (1u << PT_ITEMS) - 1u;
+        if (vec) return PT_ALL_ITEMS;
         uint32_t ok = 0;
 #pragma unroll
         for (int j = 0; j < PT_ITEMS; ++j)
