@@ -15,8 +15,9 @@ N = 1  headline workload = BASELINE.json configs[2] (the largest single-GPU conf
        The same JSON line carries, as extra fields, `configs` (BASELINE config 2 = 100M ⋈ 100M
        uniform, and 1B ⋈ 1B uniform, each timed and verified the same way) and `plan_ms`
        (end-to-end Contest::execute semantics, host pages in / host pages out, for the JOB plan
-       trees job/1a and job/13d over synthetic IMDB-shaped inputs: what the reference harness
-       times, tests/read_sql.cpp:1234-1236).
+       trees job/1a, job/13d and job/10c — the last one a 1M-row result with two VARCHAR columns —
+       over synthetic IMDB-shaped inputs: what the reference harness times,
+       tests/read_sql.cpp:1234-1236).
 N > 1  one process per GPU (torch.distributed, backend nccl = RCCL).  STRONG scaling: the same
        1B ⋈ 1B job, each rank holding 1/N of the rows of both relations; the join shards by key
        hash with one exchange step.  value = 1B probe tuples per
@@ -181,7 +182,7 @@ def run_single(name, device, dev_index, steps, warmup, verify=True, rows=None):
     return out, info
 
 
-def job_plan_ms(dev_index, queries=("1a", "13d"), repeat=3):
+def job_plan_ms(dev_index, queries=("1a", "13d", "10c"), repeat=3):
     """End-to-end plan ms, host pages in / host pages out (rj_execute + rj_result_copy_pages),
     on JOB plan trees over synthetic IMDB-shaped inputs (IMDB itself is not available offline):
     what the reference harness times around Contest::execute (tests/read_sql.cpp:1234-1236)."""
@@ -218,7 +219,7 @@ def job_plan_ms(dev_index, queries=("1a", "13d"), repeat=3):
             "input_rows": int(sum(t.num_rows for t in plan.inputs)),
             "output_rows": int(rows_out),
             "data": "synthetic IMDB-shaped (row counts = PostgreSQL Plan Rows of plans.json)",
-            "reference_published_ms": {"1a": 3315, "13d": 11770}.get(name),  # benchmarks/run_b78733e.txt:1,48 (TR PRO 7995WX, real IMDB)
+            "reference_published_ms": {"1a": 3315, "13d": 11770, "10c": 5228}.get(name),  # benchmarks/run_b78733e.txt:1,48,37 (TR PRO 7995WX, real IMDB)
         }
     ctx.destroy()
     return out

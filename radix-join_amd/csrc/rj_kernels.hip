@@ -156,39 +156,54 @@ __device__ __forceinline__ void stream_store(const OutStream& o, uint64_t row, u
 __global__ __launch_bounds__(256) void k_page_headers(const uint8_t* pages, uint32_t n_pages,
                                                       uint32_t rows_full, uint32_t* page_rows,
                                                       unsigned long long* flags) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (p >= n_pages) return;
-    const uint8_t* page = pages + (size_t)p * PAGE_BYTES;
-    const uint32_t nr = *reinterpret_cast<const uint16_t*>(page);
-    const uint32_t nb = (nr + 7) / 8;
-    const uint8_t* bm = page + PAGE_BYTES - nb;
-    bool           ones = true;
-    // full pages: 248 bitmap bytes at a dword boundary (INT32) or 126 at a halfword boundary
-    // (INT64/FP64) — one load per lane; anything else byte by byte
-    const uint32_t boff = PAGE_BYTES - nb;
-    if ((nr & 31u) == 0 && (boff & 3u) == 0) {
-        for (uint32_t k = lane; k < nb / 4; k += 64)
-            ones = ones && reinterpret_cast<const uint32_t*>(bm)[k] == 0xffffffffu;
-    } else if ((boff & 1u) == 0 && (nb & 1u) == 0) {
-        for (uint32_t k = lane; k < nb / 2; k += 64) {
-            const uint32_t rem = nr - k * 16u;
-            const uint32_t want = rem >= 16 ? 0xffffu : ((1u << rem) - 1u);
-            ones = ones && ((uint32_t)reinterpret_cast<const uint16_t*>(bm)[k] & want) == want;
+    // every workgroup walks a strip of pages (one wave per page at a time) and adds its two
+    // sums with ONE pair of global atomics: a million pages must not queue on two words
+    __shared__ unsigned long long s_irr[4], s_rows[4];
+    const uint32_t     lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    unsigned long long irr = 0, rows = 0;
+    for (uint32_t p = blockIdx.x * 4u + wid; p < n_pages; p += gridDim.x * 4u) {
+        const uint8_t* page = pages + (size_t)p * PAGE_BYTES;
+        const uint32_t nr = *reinterpret_cast<const uint16_t*>(page);
+        const uint32_t nb = (nr + 7) / 8;
+        const uint8_t* bm = page + PAGE_BYTES - nb;
+        bool           ones = true;
+        // full pages: 248 bitmap bytes at a dword boundary (INT32) or 126 at a halfword boundary
+        // (INT64/FP64) — one load per lane; anything else byte by byte
+        const uint32_t boff = PAGE_BYTES - nb;
+        if ((nr & 31u) == 0 && (boff & 3u) == 0) {
+            for (uint32_t k = lane; k < nb / 4; k += 64)
+                ones = ones && reinterpret_cast<const uint32_t*>(bm)[k] == 0xffffffffu;
+        } else if ((boff & 1u) == 0 && (nb & 1u) == 0) {
+            for (uint32_t k = lane; k < nb / 2; k += 64) {
+                const uint32_t rem = nr - k * 16u;
+                const uint32_t want = rem >= 16 ? 0xffffu : ((1u << rem) - 1u);
+                ones = ones && ((uint32_t)reinterpret_cast<const uint16_t*>(bm)[k] & want) == want;
+            }
+        } else {
+            for (uint32_t k = lane; k < nb; k += 64) {
+                const uint32_t rem = nr - k * 8u;
+                const uint32_t want = rem >= 8 ? 0xffu : ((1u << rem) - 1u);
+                ones = ones && ((bm[k] & want) == want);
+            }
         }
-    } else {
-        for (uint32_t k = lane; k < nb; k += 64) {
-            const uint32_t rem = nr - k * 8u;
-            const uint32_t want = rem >= 8 ? 0xffu : ((1u << rem) - 1u);
-            ones = ones && ((bm[k] & want) == want);
+        const bool all_ones = __ballot(!ones) == 0;
+        if (lane == 0) {
+            page_rows[p] = nr;
+            irr += !all_ones || (p + 1 < n_pages ? nr != rows_full : (nr > rows_full || nr == 0));
+            rows += nr;
         }
     }
-    const bool all_ones = __ballot(!ones) == 0;
-    if (lane != 0) return;
-    page_rows[p] = nr;
-    bool irregular = !all_ones || (p + 1 < n_pages ? nr != rows_full : (nr > rows_full || nr == 0));
-    if (irregular) atomicAdd(&flags[0], 1ull);
-    atomicAdd(&flags[1], (unsigned long long)nr);
+    if (lane == 0) {
+        s_irr[wid] = irr;
+        s_rows[wid] = rows;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long i = s_irr[0] + s_irr[1] + s_irr[2] + s_irr[3];
+        const unsigned long long r = s_rows[0] + s_rows[1] + s_rows[2] + s_rows[3];
+        if (i) atomicAdd(&flags[0], i);
+        if (r) atomicAdd(&flags[1], r);
+    }
 }
 
 // "row_idx" rule of Table::from_columnar (reference src/build_table.cpp:334-336): the
@@ -1938,7 +1953,7 @@ __global__ __launch_bounds__(256) void k_encode_nullable(const uint8_t* values, 
 void launch_page_headers(const Launch& L, const uint8_t* pages, uint32_t n_pages, uint32_t rows_full,
                          uint32_t* page_rows, unsigned long long* flags) {
     if (!n_pages) return;
-    RJ_KLAUNCH(L, "page_headers", k_page_headers, (n_pages + 3) / 4, 256, pages, n_pages,
+    RJ_KLAUNCH(L, "page_headers", k_page_headers, std::min<uint32_t>((n_pages + 3) / 4, 8192u), 256, pages, n_pages,
                rows_full, page_rows, flags);
 }
 
