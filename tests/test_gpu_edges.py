@@ -233,3 +233,35 @@ def test_tagged_table_path_forced_bits(bits, probe_dt):
             check(c, plan, small=False)
     finally:
         c.destroy()
+
+
+def test_adopted_device_tables_follow_the_same_page_rules(ctx):
+    """rj_table_adopt_device analyses pages on the GPU (k_page_headers / k_rows_beyond): trailing
+    NULL rows beyond num_rows are tolerated, a non-NULL value beyond raises "row_idx", and a column
+    whose pages are full but carry cleared bitmap bits is not addressed in place"""
+    import torch
+
+    vals = np.arange(5000, dtype=np.int32)
+    valid = np.ones(5000, bool)
+    valid[4990:] = False
+    kpages = pg.pack_fixed(vals, valid, pl.INT32)  # NULL-bearing: irregular pages
+    ppages = pg.pack_fixed(vals[:4990], None, pl.INT32)
+    other = pl.make_table([(pl.INT32, np.arange(0, 5000, 5, dtype=np.int32)), (pl.INT32, np.arange(1000, dtype=np.int32))])
+    both = [(0, pl.INT32), (1, pl.INT32)]
+
+    def adopt(num_rows, pages_list):
+        dev = [torch.from_numpy(p.copy()).cuda() for p in pages_list]
+        return ctx.adopt_device(num_rows, [pl.INT32] * len(dev), [d.data_ptr() for d in dev], [d.shape[0] for d in dev], keep=dev)
+
+    t = adopt(4990, [kpages, ppages])
+    o = ctx.upload(other)
+    host_t = pl.ColumnarTable(4990, [pl.Column(pl.INT32, kpages), pl.Column(pl.INT32, ppages)])
+    plan = join2(host_t, other, True, 0, 0, both, both, [(0, pl.INT32), (1, pl.INT32), (3, pl.INT32)])
+    res = ctx.execute_resident(plan, [t, o])
+    got = res.to_table()
+    res.free()
+    assert pl.sorted_rows(got) == pl.sorted_rows(_oracle.execute(plan))
+    t.release()
+    with pytest.raises(capi.RjError, match="row_idx"):
+        adopt(4980, [kpages, pg.pack_fixed(vals[:4980], None, pl.INT32)])  # rows 4980..4989 are non-NULL
+    o.release()
