@@ -20,6 +20,7 @@ void Tuning::from_env() {
     fine = env_int("RJ_TUNE_FINE", fine);
     pack = env_int("RJ_TUNE_PACK", pack);
     aos3 = env_int("RJ_TUNE_AOS3", aos3);
+    aos_mid = env_int("RJ_TUNE_AOS_MID", aos_mid);
     tpg1 = env_int("RJ_TUNE_TPG1", tpg1);
     bcast = env_int("RJ_TUNE_BCAST", bcast);
     diag = env_int("RJ_DIAG", diag);

@@ -94,6 +94,11 @@ struct PassParams {
     uint32_t        tiles_per_group;
     uint32_t*       hist;       // [nseg*F]      global bin totals
     uint32_t*       cursor;     // [nseg*F]      write cursors (start = exclusive scan of hist)
+    // 12-byte-tuple passes that are not the last one also write the NEXT pass' digit of every
+    // tuple as a 16-bit side array (same index as the tuple), so that the next histogram reads
+    // 2 bytes per tuple instead of fishing 4-byte keys out of 12-byte tuples; nullptr = none
+    uint16_t*       side_out;
+    uint32_t        next_shift, next_mask;
 };
 
 // ---- Build/probe -------------------------------------------------------------

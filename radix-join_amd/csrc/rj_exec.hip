@@ -334,11 +334,25 @@ class Exec {
         // one key word + a two-word carry: the LAST pass writes 12-byte tuples into one array
         // (RJ_TUNE_AOS3=0: key array + pair array, as the earlier passes do)
         P.aos3 = KW == 1 && CW == 2 && !external && !single_pass && ctx->tune.aos3 != 0;
-        BufP  A[MAX_WORDS], B[MAX_WORDS], AOS;
+        // ... and so do the passes before it (one output stream of 384-byte runs instead of a
+        // 128-byte-run key stream + a 256-byte-run pair stream; a later pass' histogram then
+        // reads a 16-bit digit side array instead of the keys)
+        // RJ_TUNE_AOS_MID: 0 never, 1 always, 2 (default) only for fine-histogram plans, which
+        // need no digit side array — with it the first pass loses more (+0.8 ms at 1 B rows) than
+        // the histogram gains (−0.4 ms): profiles/r02_y_aos_between_passes_ab.log
+        const bool aos_mid = P.aos3 && passes >= 2 &&
+                             (ctx->tune.aos_mid == 1 || (ctx->tune.aos_mid == 2 && fine));
+        BufP  A[MAX_WORDS], B[MAX_WORDS], AOS, MID[2], SIDE[2];
         Words wa{}, wb{}, waos{};
         if (P.aos3) {
             AOS = ctx->buf(std::max<uint64_t>(n, 1) * 12);
             waos.w[0] = AOS->as<uint32_t>();
+        }
+        if (aos_mid) {
+            for (uint32_t k = 0; k < std::min<uint32_t>(passes - 1, 2); ++k) {
+                MID[k] = ctx->buf(std::max<uint64_t>(n, 1) * 12);
+                if (!fine) SIDE[k] = ctx->buf(std::max<uint64_t>(n, 1) * 2);
+            }
         }
         for (int a = 0; a < (P.packed ? 1 : P.NW); ++a) {
             // a two-word carry is ONE array of 8-byte pairs (at word KW), key + one carry word
@@ -349,7 +363,7 @@ class Exec {
                 wa.w[a] = external->w[a];
                 continue;
             }
-            if (P.aos3 && passes == 1) continue;  // the only pass writes the 12-byte array
+            if ((P.aos3 && passes == 1) || aos_mid) continue;  // every pass writes 12-byte tuples
             A[a] = ctx->buf(n * wbytes);
             wa.w[a] = A[a]->as<uint32_t>();
             if (passes > (P.aos3 ? 2u : 1u)) {
@@ -420,6 +434,8 @@ class Exec {
                     pp.cursor = cursor->as<uint32_t>();
                     if (p == 0 && !ws)
                         launch_pass_hist_src(L, src, KW, pp, n_groups);
+                    else if (aos_mid && p > 0)
+                        launch_pass_hist_digits(L, SIDE[(p - 1) % 2]->as<uint16_t>(), pp, n_groups);
                     else if (P.packed)
                         launch_pass_hist_packed(L, cur.w[0], pp, n_groups);
                     else
@@ -427,7 +443,23 @@ class Exec {
                     launch_scan_segments(L, pp.hist, p == 0 ? nullptr : pp.seg_off, nseg, F,
                                          off->as<uint32_t>(), pp.cursor);
                 }
-                if (P.packed) {
+                if (aos_mid) {
+                    const bool last = p + 1 == passes;
+                    Words      o{};
+                    o.w[0] = last ? waos.w[0] : MID[p % 2]->as<uint32_t>();
+                    if (!last && !fine) {
+                        pp.side_out = SIDE[p % 2]->as<uint16_t>();
+                        pp.next_shift = shift + pbits[p];
+                        pp.next_mask = (1u << pbits[p + 1]) - 1u;
+                    }
+                    if (p == 0 && !ws)
+                        launch_pass_scatter_src(L, src, KW, CW, pp, n_groups, o, true);
+                    else if (p == 0)
+                        launch_pass_scatter_dense(L, cur, P.NW, KW, pp, n_groups, o, true);
+                    else
+                        launch_pass_scatter_aos3(L, MID[(p - 1) % 2]->as<uint32_t>(), pp, n_groups, o.w[0]);
+                    nxt = o;
+                } else if (P.packed) {
                     if (p == 0 && !ws)
                         launch_pass_scatter_src_packed(L, src, pp, n_groups, nxt.w[0]);
                     else
@@ -445,6 +477,10 @@ class Exec {
                 cur_is_a = (p % 2 == 0);
                 nxt = cur_is_a ? wb : wa;
                 if (P.aos3 && p + 2 == passes) nxt = waos;  // the next pass is the last one
+                if (aos_mid) {
+                    // (MID / SIDE buffers of a pass are read by the next one only; they go back to
+                    // the block cache when this function returns — all on one stream)
+                }
             }
             P.w = cur;
             for (int a = 0; a < P.NW; ++a) P.wbuf[a] = cur_is_a ? A[a] : B[a];

@@ -173,6 +173,8 @@ struct Tuning {
     int fine = 1;         // RJ_TUNE_FINE: fine (two-digit) histogram for plans <= 2^PT_FINEBITS partitions
     int pack = 1;         // RJ_TUNE_PACK: 0 never, 1 always, 2 fine plans only: {key, carry} pairs
     int aos3 = 1;         // RJ_TUNE_AOS3: last pass of key + two-word-carry plans writes 12-byte tuples
+    int aos_mid = 2;      // RJ_TUNE_AOS_MID: ... and so do the passes before it (+ a 16-bit digit side array
+                          // for the next histogram); 0: key array + pair array between the passes
     int tpg1 = 0;         // RJ_TUNE_TPG1: tiles per group of pass 1 (0 = auto)
     int bcast = 1;        // RJ_TUNE_BCAST: broadcast join for build sides that fit one LDS table
     int diag = 0;         // RJ_DIAG: 1 = join phase stamps, 2 = host-side timings on stderr

@@ -418,6 +418,66 @@ struct DenseLoaderT {
 
 using DenseLoader = DenseLoaderT<-1>;
 
+// One array of 12-byte {hashed key, carry lo, carry hi} tuples (what every pass of a key +
+// two-word-carry plan writes): four consecutive tuples = three 16-byte loads.
+struct Aos3Loader {
+    const uint32_t* in;
+    template <int NW>
+    __device__ __forceinline__ uint32_t load_tile(uint32_t base, uint32_t end, uint32_t (&w)[PT_ITEMS][NW]) const {
+        static_assert(NW == 3, "12-byte tuples");
+        if (base + PT_TILE <= end) {
+#pragma unroll
+            for (int v = 0; v < PT_ITEMS / 4; ++v) {
+                const uint32_t* p = in + (size_t)(base + (v * PT_THREADS + threadIdx.x) * 4) * 3;
+                const u32x4a    x = *reinterpret_cast<const u32x4a*>(p), y = *reinterpret_cast<const u32x4a*>(p + 4),
+                             z = *reinterpret_cast<const u32x4a*>(p + 8);
+                w[4 * v + 0][0] = x[0];
+                w[4 * v + 0][1] = x[1];
+                w[4 * v + 0][2] = x[2];
+                w[4 * v + 1][0] = x[3];
+                w[4 * v + 1][1] = y[0];
+                w[4 * v + 1][2] = y[1];
+                w[4 * v + 2][0] = y[2];
+                w[4 * v + 2][1] = y[3];
+                w[4 * v + 2][2] = z[0];
+                w[4 * v + 3][0] = z[1];
+                w[4 * v + 3][1] = z[2];
+                w[4 * v + 3][2] = z[3];
+            }
+            return PT_ALL_ITEMS;
+        }
+        uint32_t ok = 0;
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS; ++j) {
+            const uint32_t  i = base + j * PT_THREADS + threadIdx.x;
+            const uint32_t* p = in + (size_t)min(i, end - 1u) * 3;
+            w[j][0] = p[0];
+            w[j][1] = p[1];
+            w[j][2] = p[2];
+            ok |= (uint32_t)(i < end) << j;
+        }
+        return ok;
+    }
+};
+
+// The side array of 16-bit digits a 12-byte-tuple pass wrote for its successor: the histogram
+// of that successor reads 2 bytes per tuple.  key_tile hands the digit back in the bit position
+// the histogram kernel takes it from.
+struct DigitLoader {
+    const uint16_t* digits;
+    uint32_t        shift;
+    __device__ __forceinline__ uint32_t key_tile(uint32_t base, uint32_t end, uint32_t (&hk)[PT_ITEMS]) const {
+        uint32_t ok = 0;
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS; ++j) {
+            const uint32_t i = base + j * PT_THREADS + threadIdx.x;
+            hk[j] = (uint32_t)digits[min(i, end - 1u)] << shift;
+            ok |= (uint32_t)(i < end) << j;
+        }
+        return ok;
+    }
+};
+
 // Partitioned tuples of ONE key word + ONE carry word can also be kept packed: an array of
 // 8-byte {hashed key, carry} pairs instead of two word arrays (see k_pass_scatter_packed).
 struct PackedLoader {
@@ -880,10 +940,12 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassPara
                     if (gi < total) {
                         const uint32_t v = s_k[i];
                         const uint2    c = s_p[i];
-                        uint32_t*      o = out.w[0] + (size_t)(s_delta[(v >> pp.shift) & mask] + gi) * 3u;
+                        const uint32_t g = s_delta[(v >> pp.shift) & mask] + gi;
+                        uint32_t*      o = out.w[0] + (size_t)g * 3u;
                         o[0] = v;
                         o[1] = c.x;
                         o[2] = c.y;
+                        if (pp.side_out) pp.side_out[g] = (uint16_t)((v >> pp.next_shift) & pp.next_mask);
                     }
                 }
                 lds_barrier();
@@ -1073,10 +1135,10 @@ enum { OM_GENERIC = 0, OM_PAGED32 = 1, OM_DENSE32 = 2, OM_P32_64_64 = 3 };
     } while (0)
 
 // PK: bit 0 = the build side, bit 1 = the probe side is a packed {hashed key, carry} array
-// TG: "tagged" table for one key word + a two-word build carry when the plan has >= 17 radix
+// TG: "tagged" table for one key word + a two-word build carry when the plan has >= 14 radix
 //     bits.  All hashed keys of a partition share their low radix bits, so the remaining
-//     (<= 15) high bits identify a key inside its partition: a slot is ONE word
-//     {tag16 | build tuple index << 16} and the carries sit densely, indexed by build tuple.
+//     (<= 18) high bits identify a key inside its partition: a slot is ONE word
+//     {tag (19 bits) | build tuple index << 19} and the carries sit densely, indexed by build tuple.
 //     Table = 32 KiB of slots + 32 KiB of carries (instead of three 32 KiB word arrays), so
 //     two 512-thread workgroups share a CU and overlap their phases like the two-word join.
 template <int KW, int CWR, int CWS, int OM, int PK, int TG>
@@ -1392,7 +1454,10 @@ __global__ __launch_bounds__(jn_threads(TG ? 2 : KW + CWR), jn_min_waves(TG ? 2 
                 rem >>= b;
             }
         }
-        // TG: no tag has its bit 15 set (tags are < 2^15) and no build index reaches 0xffff
+        // TG: no build index reaches 0x1fff (a table holds JN_RMAX = 4096 tuples), so no slot equals
+        // the all-ones word, and with >= 14 radix bits no tag (<= 18 bits) equals its 19 tag bits
+        constexpr uint32_t TGB = 19, TGM = (1u << TGB) - 1u;
+        static_assert(JN_RMAX <= (1u << (32 - TGB)) - 1u, "build index field of a tagged slot");
         const uint32_t EMPTY = TG ? 0xffffffffu : (qbits ^ 1u);
 
         for (uint32_t rc = cur.rbeg; rc < cur.rend; rc += JN_RMAX) {
@@ -1420,7 +1485,7 @@ __global__ __launch_bounds__(jn_threads(TG ? 2 : KW + CWR), jn_min_waves(TG ? 2 
                         if (pos < 4) {
                             const uint32_t slot = b * 4 + pos;
                             if constexpr (TG) {
-                                t_w[0][slot] = (rw[j][0] >> jp.radix_bits) | (i << 16);
+                                t_w[0][slot] = (rw[j][0] >> jp.radix_bits) | (i << TGB);
                             } else {
 #pragma unroll
                                 for (int a = 0; a < RW; ++a) t_w[a][slot] = rw[j][a];
@@ -1458,11 +1523,11 @@ __global__ __launch_bounds__(jn_threads(TG ? 2 : KW + CWR), jn_min_waves(TG ? 2 
                             const uint4 kv = *reinterpret_cast<const uint4*>(&t_w[0][b * 4]);
                             if constexpr (TG) {
                                 const uint32_t tag = sw[j][0] >> jp.radix_bits;
-                                const uint32_t eq = (uint32_t)((kv.x & 0xffffu) == tag) | ((uint32_t)((kv.y & 0xffffu) == tag) << 1) |
-                                                    ((uint32_t)((kv.z & 0xffffu) == tag) << 2) | ((uint32_t)((kv.w & 0xffffu) == tag) << 3);
+                                const uint32_t eq = (uint32_t)((kv.x & TGM) == tag) | ((uint32_t)((kv.y & TGM) == tag) << 1) |
+                                                    ((uint32_t)((kv.z & TGM) == tag) << 2) | ((uint32_t)((kv.w & TGM) == tag) << 3);
                                 if (eq) {
                                     // f = build tuple index of the FIRST match (its carries: t_c2[f])
-                                    if (m[j] == 0) f[j] = ((eq & 1u) ? kv.x : (eq & 2u) ? kv.y : (eq & 4u) ? kv.z : kv.w) >> 16;
+                                    if (m[j] == 0) f[j] = ((eq & 1u) ? kv.x : (eq & 2u) ? kv.y : (eq & 4u) ? kv.z : kv.w) >> TGB;
                                     m[j] += (uint32_t)__popc(eq);
                                 }
                                 if (kv.w == EMPTY) break;
@@ -1577,10 +1642,10 @@ __global__ __launch_bounds__(jn_threads(TG ? 2 : KW + CWR), jn_min_waves(TG ? 2 
                                     const uint32_t sv[4] = {kv.x, kv.y, kv.z, kv.w};
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) {
-                                        if ((sv[e] & 0xffffu) == tag && left) {
+                                        if ((sv[e] & TGM) == tag && left) {
                                             if (left != m[j]) {  // the first match went out above
                                                 ++row;
-                                                const uint2 c = t_c2[sv[e] >> 16];
+                                                const uint2 c = t_c2[sv[e] >> TGB];
                                                 emit_row(row, klo, khi, c.x, c.y, p0, p1);
                                             }
                                             --left;
@@ -2105,6 +2170,21 @@ void launch_pass_scatter_dense(const Launch& L, const Words& in, int n_words, in
     }
 }
 
+void launch_pass_hist_digits(const Launch& L, const uint16_t* digits, const PassParams& pp, uint32_t n_groups) {
+    if (!n_groups) return;
+    DigitLoader ld{digits, pp.shift};
+    RJ_KLAUNCH(L, "pass2_hist", (k_pass_hist<DigitLoader>), n_groups, PT_THREADS, ld, pp);
+}
+
+void launch_pass_scatter_aos3(const Launch& L, const uint32_t* in_tuples, const PassParams& pp, uint32_t n_groups,
+                              uint32_t* out_tuples) {
+    if (!n_groups) return;
+    Words out{};
+    out.w[0] = out_tuples;
+    RJ_KLAUNCH(L, "pass2_scatter", (k_pass_scatter<3, Aos3Loader, 1, true>), n_groups, PT_THREADS,
+               Aos3Loader{in_tuples}, pp, out);
+}
+
 void launch_pass_hist_packed(const Launch& L, const uint32_t* in_pairs, const PassParams& pp,
                              uint32_t n_groups) {
     if (!n_groups) return;
@@ -2139,7 +2219,7 @@ void launch_heavy_tasks(const Launch& L, const uint32_t* offR, const uint32_t* o
 #define RJ_TG_ENABLE 1
 #endif
 static bool join_tagged(int key_words, int cw_build, const JoinParams& jp) {
-    return RJ_TG_ENABLE && key_words == 1 && cw_build == 2 && jp.radix_bits >= 17 && jp.radix_bits <= 31;
+    return RJ_TG_ENABLE && key_words == 1 && cw_build == 2 && jp.radix_bits >= 14 && jp.radix_bits <= 31;
 }
 
 template <int KW, int CWR, int CWS, int PK>

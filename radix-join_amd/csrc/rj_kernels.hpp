@@ -72,6 +72,13 @@ void launch_pass_hist_dense(const Launch& L, const Words& in, const PassParams& 
 void launch_pass_scatter_dense(const Launch& L, const Words& in, int n_words, int pair_word,
                                const PassParams& pp, uint32_t n_groups, const Words& out, bool aos3 = false);
 
+// 12-byte tuples between the passes of a key + two-word-carry plan: the histogram of a later
+// pass reads the 16-bit digit side array its predecessor wrote (PassParams::side_out), the
+// scatter reads and writes 12-byte tuples
+void launch_pass_hist_digits(const Launch& L, const uint16_t* digits, const PassParams& pp, uint32_t n_groups);
+void launch_pass_scatter_aos3(const Launch& L, const uint32_t* in_tuples, const PassParams& pp, uint32_t n_groups,
+                              uint32_t* out_tuples);
+
 // Packed layout ({hashed key, carry} pairs in one array) for one key word + one carry word.
 void launch_pass_hist_packed(const Launch& L, const uint32_t* in_pairs, const PassParams& pp,
                              uint32_t n_groups);

@@ -206,10 +206,11 @@ def test_trailing_null_rows_beyond_num_rows_are_tolerated(ctx):
         _oracle.execute(plan)
 
 
-@pytest.mark.parametrize("bits,probe_dt", [(17, pl.INT64), (18, pl.INT32), (21, pl.INT64)])
+@pytest.mark.parametrize("bits,probe_dt", [(13, pl.INT32), (14, pl.INT64), (16, pl.INT64), (17, pl.INT64), (18, pl.INT32), (21, pl.INT64)])
 def test_tagged_table_path_forced_bits(bits, probe_dt):
-    """One key word + two-word build carry with >= 17 radix bits takes the "tagged" LDS table
-    ({tag16 | build index} slots + dense carries, k_join TG=1).  Duplicate build keys (the
+    """One key word + two-word build carry with >= 14 radix bits takes the "tagged" LDS table (13 bits: the
+    generic table, kept in the sweep)
+    ({19-bit tag | build index} slots + dense carries, k_join TG=1).  Duplicate build keys (the
     re-walk that emits every further match), NULL keys, a hot probe key (heavy-task path) and
     misses, against the oracle."""
     c = capi.Context(radix_bits=bits)
