@@ -84,3 +84,53 @@ def test_two_word_carry_path_50m_vs_oracle():
     want = _oracle.execute(p)
     assert want.num_rows == n
     assert dg == pl.table_digest(want)
+
+
+def test_sharded_config3_shape_eight_virtual_ranks_200m():
+    """The sharded path at a size where every count is far beyond 16 bits: 200 M ⋈ 200 M of
+    config 3's shape (Zipf-0.9 probe keys, INT64 payloads) over eight virtual ranks on this one
+    GPU (rj_execute_sharded, peer-copy transport).  Closed form: every rank's output rows name a
+    build row that holds their key (the build keys are a bijection of the global row index),
+    and over all ranks the result has |S| rows with the probe side's key sum and payload checksum."""
+    import torch
+
+    world, total = 8, 200_000_000
+    ctx = capi.Context(devices=[0] * world)
+    tables, rels = [], []
+    try:
+        for r in range(world):
+            rel = wl.make_relations("config3", torch.device("cuda"), rows=total, rank=r, world=world, sharded=True)
+            lane = ctx.lane(r)
+            tables.append([wl.adopt(lane, [rel.rk, rel.rp]), wl.adopt(lane, [rel.sk, rel.sp])])
+            rels.append(rel)
+        results = ctx.execute_sharded(wl.join_plan(pl.INT64), tables)
+        rows = 0
+        sum_key = want_key = 0
+        sum_mix = want_mix = 0
+        mask = 0xFFFFFFFFFFFFFFFF
+        for res, rel in zip(results, rels):
+            n_out = res.num_rows
+            rows += n_out
+            assert n_out > 0.5 * total / world  # hash sharding spreads even a Zipf probe side
+            key2d, _ = wl.result_column(res, 0, n_out)
+            bp2d, _ = wl.result_column(res, 1, n_out)
+            pp2d, _ = wl.result_column(res, 2, n_out)
+            key = key2d.reshape(-1)[:n_out].to(torch.int64)
+            bpay = bp2d.reshape(-1)[:n_out]
+            ppay = pp2d.reshape(-1)[:n_out]
+            assert bool((bpay % wl.PAY_MUL == 0).all()) and bool((ppay % wl.PAY_MUL == 0).all())
+            brow = bpay // wl.PAY_MUL
+            assert bool((wl.build_key_of_row(brow, total) == key).all()), "output key differs from its build row's key"
+            sum_key += int(key.sum())
+            sum_mix = (sum_mix + int(wl._mix64(ppay).sum())) & mask
+            want_key += int(rel.sk.to(torch.int64).sum())
+            want_mix = (want_mix + int(wl._mix64(rel.sp).sum())) & mask
+            res.free()
+        assert rows == total
+        assert sum_key == want_key and sum_mix == want_mix
+    finally:
+        for row in tables:
+            for t in row:
+                t.release()
+        ctx.destroy()
+        torch.cuda.empty_cache()
