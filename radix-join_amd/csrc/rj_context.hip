@@ -180,6 +180,11 @@ void* Context::staging(size_t bytes) {
     return pinned;
 }
 
+void* Context::small_pinned() {
+    if (!pinned_small) RJ_HIP(hipHostMalloc(&pinned_small, SMALL_PINNED, hipHostMallocDefault));
+    return pinned_small;
+}
+
 int Context::compute_units() {
     if (n_cu <= 0) {
         int v = 0;

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
+#include <functional>
 #include <set>
 
 #include "rj_internal.hpp"
@@ -300,8 +301,12 @@ class Exec {
     // Source = columns (`src`: page decode, NULL drop and hashing ride on the first pass) or
     // tuples already in the partition layout (`ws`, sharded stage B).
     // `external`: caller-owned arrays that receive the output of a single-pass partition
+    // after_offsets (optional): called once the FIRST pass' partition offsets are enqueued to be
+    // computed, before its scatter is enqueued — a caller that needs the counts on the host
+    // (the sharded join's stage A) copies them out ahead of the scatter.
     Parted partition(const TupleSrc* srcp, const WordSrc* ws, int KW, int CW, uint32_t bits,
-                     uint32_t shift0 = 0, bool single_pass = false, const Words* external = nullptr) {
+                     uint32_t shift0 = 0, bool single_pass = false, const Words* external = nullptr,
+                     const std::function<void(const uint32_t*)>* after_offsets = nullptr) {
         Parted P;
         P.NW = KW + CW;
         const TupleSrc none{};
@@ -443,6 +448,7 @@ class Exec {
                     launch_scan_segments(L, pp.hist, p == 0 ? nullptr : pp.seg_off, nseg, F,
                                          off->as<uint32_t>(), pp.cursor);
                 }
+                if (p == 0 && after_offsets) (*after_offsets)(off->as<uint32_t>());
                 if (aos_mid) {
                     const bool last = p + 1 == passes;
                     Words      o{};
@@ -1253,11 +1259,13 @@ class ShardedExec {
             std::vector<uint32_t> off;     // [world + 1] host copy of A.off
             BufP                  recv[MAX_WORDS];
             WordSrc               ws;      // what arrived
-            Ev                    ready, done;
+            Ev                    ready, done, counted;
             Parted                P;       // stage B partitions
         };
         std::vector<SideX> bx((size_t)nl_), px((size_t)nl_);
         const uint32_t     shiftA = rb_ ? 32 - rb_ : 31;
+        if ((size_t)world_ + 1 > Context::SMALL_PINNED / 8)
+            throw_fmt(RJ_ERR_UNSUPPORTED, "sharded join: more than %zu ranks", Context::SMALL_PINNED / 8 - 1);
         for (int l = 0; l < nl_; ++l) {
             use(l);
             Exec&    E = *ex_[l];
@@ -1266,17 +1274,32 @@ class ShardedExec {
                 Exec::Side& s = side == 0 ? st[l].bs() : st[l].ps();
                 SideX&      X = side == 0 ? bx[l] : px[l];
                 TupleSrc    src = E.make_src(st[l], s, js);
-                X.A = E.partition(&src, nullptr, KW, s.CW, rb_, shiftA, /*single pass*/ true);
-                X.off.assign((size_t)world_ + 1, 0);
-                RJ_HIP(hipMemcpyAsync(X.off.data(), X.A.off->p, ((size_t)world_ + 1) * 4,
-                                      hipMemcpyDeviceToHost, c->stream));
                 X.ready.make();
                 X.done.make();
+                X.counted.make();
+                // the per-owner counts leave for the host BEFORE the scatter is enqueued: the
+                // host sizes and starts the exchange of the build side while the probe side's
+                // scatter is still running
+                uint32_t* host_off = static_cast<uint32_t*>(c->small_pinned()) + (size_t)side * (Context::SMALL_PINNED / 8);
+                const std::function<void(const uint32_t*)> counts_out = [&](const uint32_t* off) {
+                    RJ_HIP(hipMemcpyAsync(host_off, off, ((size_t)world_ + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+                    RJ_HIP(hipEventRecord(X.counted.e, c->stream));
+                };
+                X.A = E.partition(&src, nullptr, KW, s.CW, rb_, shiftA, /*single pass*/ true, nullptr, &counts_out);
                 RJ_HIP(hipEventRecord(X.ready.e, c->stream));
             }
         }
-        sync_all();  // the offsets are on the host now
-        lap("stage A (both sides)");
+        for (int l = 0; l < nl_; ++l) {
+            use(l);
+            Context* c = g_->lane(l);
+            for (int side = 0; side < 2; ++side) {
+                SideX& X = side == 0 ? bx[l] : px[l];
+                RJ_HIP(hipEventSynchronize(X.counted.e));
+                const uint32_t* host_off = static_cast<const uint32_t*>(c->small_pinned()) + (size_t)side * (Context::SMALL_PINNED / 8);
+                X.off.assign(host_off, host_off + world_ + 1);
+            }
+        }
+        lap("stage A (histograms on the host; scatters may still run)");
 
         // ---- who sends how much to whom: cnt[src rank][side * world + dst rank]
         for (int l = 0; l < nl_; ++l) {

@@ -199,7 +199,9 @@ struct Context {
     // pinned staging for H2D / D2H of page images
     void*  pinned = nullptr;
     size_t pinned_bytes = 0;
-    void*  pinned_small = nullptr;  // 4 KiB for counters
+    static constexpr size_t SMALL_PINNED = 4096;
+    void*  pinned_small = nullptr;  // SMALL_PINNED bytes for counters that travel to the host
+    void*  small_pinned();
     // second lane (rj_execute): inputs are uploaded by a helper thread on their own stream
     // while the plan already runs on `stream`
     hipStream_t copy_stream = nullptr;
