@@ -160,6 +160,10 @@ def main(args, rank, world, dev_index, device):
                 "arch": info["arch"],
                 "verified": digest,
             },
+            # redistribution as rank 0 saw it: ms per step on its exchange stream, from "my slices
+            # are ready" to "everything has left / arrived" (includes waiting for slower peers; it
+            # overlaps the probe side's stage-A scatter and the build side's local passes)
+            "exchange_ms": {s["name"]: s["total_ms"] / args.steps for s in (stats or []) if s["name"].startswith("exchange")},
             # rank 0's kernels on its 1/N share (the exchange itself is not a kernel of ours)
             "roofline": bench.roofline(stats, rel.n, rel.n, args.steps, 8 if rel.payload64 else 4, f"{name}_x{world}") if stats else None,
         }

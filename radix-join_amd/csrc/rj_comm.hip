@@ -177,14 +177,21 @@ void Comm::allgather_u64(const std::vector<std::vector<uint64_t>>& vals, size_t 
 }
 
 void Comm::all_to_all(const std::vector<std::vector<XferSpec>>& specs, const std::vector<hipEvent_t>& ready,
-                      std::vector<hipEvent_t>& done) {
+                      std::vector<hipEvent_t>& done, const char* name) {
     const int nl = n_local();
+    // profiling contexts: start/stop events on each lane's exchange stream
+    std::vector<hipEvent_t> t0((size_t)nl, nullptr), t1((size_t)nl, nullptr);
+    for (int l = 0; l < nl; ++l) {
+        RJ_HIP(hipSetDevice(lanes_[l]->device));  // (events belong to the device they are made on)
+        if (!lanes_[l]->prof.timed(name, &t0[l], &t1[l])) t0[l] = t1[l] = nullptr;
+    }
     if (mode_ == P2P) {
         // a copy touches the sender's AND the receiver's buffer: every exchange stream waits for
         // every lane's `ready`
         for (int l = 0; l < nl; ++l) {
             RJ_HIP(hipSetDevice(lanes_[l]->device));
             for (int o = 0; o < nl; ++o) RJ_HIP(hipStreamWaitEvent(xfer_[l], ready[o], 0));
+            if (t0[l]) RJ_HIP(hipEventRecord(t0[l], xfer_[l]));
         }
         for (int s = 0; s < nl; ++s) {
             RJ_HIP(hipSetDevice(lanes_[s]->device));
@@ -209,6 +216,7 @@ void Comm::all_to_all(const std::vector<std::vector<XferSpec>>& specs, const std
         for (int l = 0; l < nl; ++l) {
             RJ_HIP(hipSetDevice(lanes_[l]->device));
             for (int s = 0; s < nl; ++s) RJ_HIP(hipStreamWaitEvent(xfer_[l], sent_[s], 0));
+            if (t1[l]) RJ_HIP(hipEventRecord(t1[l], xfer_[l]));
             RJ_HIP(hipEventRecord(done[l], xfer_[l]));
         }
     } else {
@@ -216,6 +224,7 @@ void Comm::all_to_all(const std::vector<std::vector<XferSpec>>& specs, const std
         for (int l = 0; l < nl; ++l) {
             RJ_HIP(hipSetDevice(lanes_[l]->device));
             RJ_HIP(hipStreamWaitEvent(xfer_[l], ready[l], 0));
+            if (t0[l]) RJ_HIP(hipEventRecord(t0[l], xfer_[l]));
         }
         // slices travel in pieces of at most 1 GiB (both ends cut the same total the same
         // way): multi-GiB point-to-point operations are outside what RCCL is exercised with
@@ -237,6 +246,7 @@ void Comm::all_to_all(const std::vector<std::vector<XferSpec>>& specs, const std
         RJ_NCCL(R.GroupEnd());
         for (int l = 0; l < nl; ++l) {
             RJ_HIP(hipSetDevice(lanes_[l]->device));
+            if (t1[l]) RJ_HIP(hipEventRecord(t1[l], xfer_[l]));
             RJ_HIP(hipEventRecord(done[l], xfer_[l]));
         }
     }

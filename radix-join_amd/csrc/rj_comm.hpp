@@ -54,8 +54,10 @@ class Comm {
     // (recorded on lane l's compute stream once its send buffers are complete).  On return
     // done[l] has been recorded: lane l's recv buffers are complete when it fires.  Buffers must
     // stay alive until then.
+    // `name`: what a profiling context books the exchange under (time on the exchange stream of
+    // each local rank from "my send buffers are ready" to "everything of mine has arrived / left")
     void all_to_all(const std::vector<std::vector<XferSpec>>& specs, const std::vector<hipEvent_t>& ready,
-                    std::vector<hipEvent_t>& done);
+                    std::vector<hipEvent_t>& done, const char* name);
 
     hipStream_t xfer_stream(int lane) const { return xfer_[lane]; }
 

@@ -120,7 +120,7 @@ hipEvent_t Profiler::get_event() {
 // recorded by the launch itself (start/stop timestamps of the dispatch), not by separate
 // event packets around it.
 static bool hot_kernel(const char* n) {
-    return !strncmp(n, "pass", 4) || !strncmp(n, "join_build", 10);
+    return !strncmp(n, "pass", 4) || !strncmp(n, "join_build", 10) || !strncmp(n, "exchange", 8);
 }
 
 bool Profiler::timed(const char* name, hipEvent_t* start, hipEvent_t* stop) {

@@ -1367,7 +1367,7 @@ class ShardedExec {
                 done.push_back(X.done.e);
             }
             if (comm_) {
-                comm_->all_to_all(specs, ready, done);
+                comm_->all_to_all(specs, ready, done, side == 0 ? "exchange_build" : "exchange_probe");
             } else {  // one rank, no transport: the slice is the whole
                 use(0);
                 for (const XferSpec& sp : specs[0])
