@@ -850,7 +850,7 @@ __global__ __launch_bounds__(PT_MAXF) void k_scan_fine(const uint32_t* fine, uin
 
 // ================================================================ K4 scatter
 // Scatter half of the radix partition (reference counterpart: the serial
-// scatter src/execute.cpp:175-184).  Per tile of 8192 tuples:
+// scatter src/execute.cpp:175-184).  Per tile of PT_TILE (16384) tuples:
 //   1. every tuple takes its rank inside its digit from an LDS atomic add;
 //   2. the digit counters are scanned (wave shuffles) into LDS positions;
 //   3. per word array the tile is written to LDS in digit order, then copied out
@@ -2214,7 +2214,7 @@ void launch_heavy_tasks(const Launch& L, const uint32_t* offR, const uint32_t* o
                n_heavy, max_tasks);
 }
 
-// tagged table (see k_join): one key word + two-word build carry, >= 17 radix bits
+// tagged table (see k_join): one key word + two-word build carry, >= 14 radix bits
 #ifndef RJ_TG_ENABLE
 #define RJ_TG_ENABLE 1
 #endif
