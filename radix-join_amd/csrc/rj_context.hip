@@ -22,6 +22,9 @@ void Tuning::from_env() {
     aos3 = env_int("RJ_TUNE_AOS3", aos3);
     aos_mid = env_int("RJ_TUNE_AOS_MID", aos_mid);
     tpg1 = env_int("RJ_TUNE_TPG1", tpg1);
+    xcd_split = env_int("RJ_TUNE_XCD_SPLIT", xcd_split);
+    tpg2 = env_int("RJ_TUNE_TPG2", tpg2);
+    xcd_min_rows = env_int("RJ_TUNE_XCD_MIN_ROWS", xcd_min_rows);
     bcast = env_int("RJ_TUNE_BCAST", bcast);
     diag = env_int("RJ_DIAG", diag);
     varchar_dev_rows = env_int("RJ_TUNE_VARCHAR_DEV", varchar_dev_rows);

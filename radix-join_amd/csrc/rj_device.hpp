@@ -92,8 +92,17 @@ struct PassParams {
     uint32_t        shift;      // digit = (word0 >> shift) & (F-1)
     uint32_t        fanout_log2;
     uint32_t        tiles_per_group;
-    uint32_t*       hist;       // [nseg*F]      global bin totals
-    uint32_t*       cursor;     // [nseg*F]      write cursors (start = exclusive scan of hist)
+    uint32_t*       hist;       // [nseg*F << xcd_log2]  global bin totals
+    uint32_t*       cursor;     // [nseg*F << xcd_log2]  write cursors (start = exclusive scan of hist)
+    // 3: every partition's range is cut into 8 sub-ranges, one per XCD (workgroup g counts and
+    // writes into sub-range g & 7 — workgroups go round-robin over the XCDs), so that the runs
+    // next to each other in memory were written through the SAME L2, which can then complete
+    // the lines they share before writing them back; 0: one range per partition
+    uint32_t        xcd_log2;
+    // passes over several segments: workgroup b takes group (b & 7) * ceil(G / 8) + (b >> 3), i.e.
+    // every XCD walks its own contiguous eighth of the groups — the workgroups that write into
+    // one segment's partitions at the same time then share an L2
+    uint32_t        xcd_remap;
     // 12-byte-tuple passes that are not the last one also write the NEXT pass' digit of every
     // tuple as a 16-bit side array (same index as the tuple), so that the next histogram reads
     // 2 bytes per tuple instead of fishing 4-byte keys out of 12-byte tuples; nullptr = none

@@ -418,7 +418,15 @@ class Exec {
             } else {
                     pp.tiles_per_group = tiles_per_group(n / nseg + 1, 16);
                     uint64_t gt = (uint64_t)pp.tiles_per_group * PT_TILE;
+                    if (ctx->tune.tpg2 > 0) {
+                        pp.tiles_per_group = (uint32_t)ctx->tune.tpg2;
+                        gt = (uint64_t)pp.tiles_per_group * PT_TILE;
+                    }
                     n_groups = (uint32_t)(n / gt + nseg);  // upper bound; exact count lives on device
+                    if (ctx->tune.xcd_split && n >= (uint64_t)ctx->tune.xcd_min_rows) {
+                        pp.xcd_remap = 1;
+                        n_groups += 8;  // 8 * ceil(G / 8) workgroups
+                    }
                     grp_start = ctx->buf(((uint64_t)nseg + 1) * 4);
                     launch_group_table(L, seg_off->as<uint32_t>(), nseg, (uint32_t)gt,
                                        grp_start->as<uint32_t>());
@@ -431,10 +439,12 @@ class Exec {
                     cursor = p == 0 ? coarse_cursor : fine_cursor;
                     pp.cursor = cursor->as<uint32_t>();
                 } else {
-                    hist = ctx->buf(bins * 4);
+                    // sub-ranges per XCD only where a partition gets many runs (big inputs)
+                    pp.xcd_log2 = (ctx->tune.xcd_split && p == 0 && n >= (uint64_t)ctx->tune.xcd_min_rows) ? 3u : 0u;
+                    hist = ctx->buf((bins << pp.xcd_log2) * 4);
                     off = ctx->buf((bins + 1) * 4);
-                    cursor = ctx->buf(bins * 4);
-                    RJ_HIP(hipMemsetAsync(hist->p, 0, bins * 4, ctx->stream));
+                    cursor = ctx->buf((bins << pp.xcd_log2) * 4);
+                    RJ_HIP(hipMemsetAsync(hist->p, 0, (bins << pp.xcd_log2) * 4, ctx->stream));
                     pp.hist = hist->as<uint32_t>();
                     pp.cursor = cursor->as<uint32_t>();
                     if (p == 0 && !ws)
@@ -445,7 +455,7 @@ class Exec {
                         launch_pass_hist_packed(L, cur.w[0], pp, n_groups);
                     else
                         launch_pass_hist_dense(L, cur, pp, n_groups);
-                    launch_scan_segments(L, pp.hist, p == 0 ? nullptr : pp.seg_off, nseg, F,
+                    launch_scan_segments(L, pp.hist, p == 0 ? nullptr : pp.seg_off, nseg, F, pp.xcd_log2,
                                          off->as<uint32_t>(), pp.cursor);
                 }
                 if (p == 0 && after_offsets) (*after_offsets)(off->as<uint32_t>());

@@ -176,6 +176,9 @@ struct Tuning {
     int aos_mid = 2;      // RJ_TUNE_AOS_MID: ... and so do the passes before it (+ a 16-bit digit side array
                           // for the next histogram); 0: key array + pair array between the passes
     int tpg1 = 0;         // RJ_TUNE_TPG1: tiles per group of pass 1 (0 = auto)
+    int tpg2 = 0;         // RJ_TUNE_TPG2: tiles per group of the later passes (0 = auto)
+    int xcd_min_rows = 64 << 20;  // RJ_TUNE_XCD_MIN_ROWS: ... for passes over at least this many tuples
+    int xcd_split = 1;    // RJ_TUNE_XCD_SPLIT: XCD-aware output placement of the big passes (PassParams::xcd_log2, xcd_remap)
     int bcast = 1;        // RJ_TUNE_BCAST: broadcast join for build sides that fit one LDS table
     int diag = 0;         // RJ_DIAG: 1 = join phase stamps, 2 = host-side timings on stderr
     int varchar_dev_rows = 200000;  // RJ_TUNE_VARCHAR_DEV: root VARCHAR columns of at least this many

@@ -306,17 +306,25 @@ __global__ __launch_bounds__(1024) void k_scan_bins(const uint32_t* in, uint32_t
 // independently instead of one workgroup walking all nseg*F bins.
 __global__ __launch_bounds__(PT_MAXF) void k_scan_segments(const uint32_t* hist,
                                                            const uint32_t* seg_off, uint32_t nseg,
-                                                           uint32_t F, uint32_t* off,
+                                                           uint32_t F, uint32_t xcd_log2, uint32_t* off,
                                                            uint32_t* cursor) {
     __shared__ uint32_t s_wsum[PT_MAXF / 64];
-    const uint32_t      seg = blockIdx.x, d = threadIdx.x;
-    const uint32_t      v = d < F ? hist[(size_t)seg * F + d] : 0u;
+    const uint32_t      seg = blockIdx.x, d = threadIdx.x, X = 1u << xcd_log2;
+    // a partition's sub-ranges (one per XCD, see PassParams::xcd_log2) lie one behind the other
+    const size_t        b0 = ((size_t)seg * F + d) << xcd_log2;
+    uint32_t            v = 0;
+    if (d < F)
+        for (uint32_t x = 0; x < X; ++x) v += hist[b0 + x];
     uint32_t            total;
     const uint32_t      ex = block_excl_scan(v, s_wsum, total);
     const uint32_t      base = seg_off ? seg_off[seg] : 0u;
     if (d < F) {
         off[(size_t)seg * F + d] = base + ex;
-        cursor[(size_t)seg * F + d] = base + ex;
+        uint32_t at = base + ex;
+        for (uint32_t x = 0; x < X; ++x) {
+            cursor[b0 + x] = at;
+            at += hist[b0 + x];
+        }
     }
     if (seg + 1 == nseg && d == 0) off[(size_t)nseg * F] = base + total;
 }
@@ -725,7 +733,13 @@ __device__ __forceinline__ bool group_range(const PassParams& pp, uint32_t g, ui
         end = (uint32_t)min((uint64_t)pp.n, b + gt);
         return true;
     }
-    if (g >= pp.grp_start[pp.nseg]) return false;
+    const uint32_t G = pp.grp_start[pp.nseg];
+    if (pp.xcd_remap) {
+        const uint32_t per = (G + 7u) >> 3;
+        if ((g >> 3) >= per) return false;
+        g = (g & 7u) * per + (g >> 3);
+    }
+    if (g >= G) return false;
     uint32_t lo = 0, hi = pp.nseg;  // largest s with grp_start[s] <= g
     while (hi - lo > 1) {
         uint32_t mid = (lo + hi) >> 1;
@@ -764,7 +778,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_hist(Loader ld, PassParams 
     lds_barrier();
     for (uint32_t d = threadIdx.x; d < F; d += PT_THREADS) {
         uint32_t c = s_h[d];
-        if (c) atomicAdd(&pp.hist[(size_t)seg * F + d], c);
+        if (c) atomicAdd(&pp.hist[(((size_t)seg * F + d) << pp.xcd_log2) | (blockIdx.x & ((1u << pp.xcd_log2) - 1u))], c);
     }
 }
 
@@ -907,7 +921,9 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassPara
         // Thread d reserves digit d's range of this tile with one global atomic; its round
         // trip is not waited for until word 0 has been staged.
         uint32_t c = threadIdx.x < F ? s_cnt[threadIdx.x] : 0u;
-        if (c) run = atomicAdd(&pp.cursor[(size_t)seg * F + threadIdx.x], c);
+        if (c)
+            run = atomicAdd(&pp.cursor[(((size_t)seg * F + threadIdx.x) << pp.xcd_log2) |
+                                       (blockIdx.x & ((1u << pp.xcd_log2) - 1u))], c);
         uint32_t total;
         uint32_t ex = block_excl_scan(c, s_wsum, total);
         if (threadIdx.x < F) s_base[threadIdx.x] = ex;
@@ -1048,7 +1064,9 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter_packed(Loader ld, P
         lds_barrier();
 
         uint32_t c = threadIdx.x < F ? s_cnt[threadIdx.x] : 0u;
-        if (c) run = atomicAdd(&pp.cursor[(size_t)seg * F + threadIdx.x], c);
+        if (c)
+            run = atomicAdd(&pp.cursor[(((size_t)seg * F + threadIdx.x) << pp.xcd_log2) |
+                                       (blockIdx.x & ((1u << pp.xcd_log2) - 1u))], c);
         uint32_t total;
         uint32_t ex = block_excl_scan(c, s_wsum, total);
         if (threadIdx.x < F) s_base[threadIdx.x] = ex;
@@ -2047,8 +2065,8 @@ void launch_scan_bins(const Launch& L, const uint32_t* in, uint32_t n, uint32_t*
 }
 
 void launch_scan_segments(const Launch& L, const uint32_t* hist, const uint32_t* seg_off,
-                          uint32_t nseg, uint32_t F, uint32_t* off, uint32_t* cursor) {
-    RJ_KLAUNCH(L, "scan_segments", k_scan_segments, nseg, PT_MAXF, hist, seg_off, nseg, F, off,
+                          uint32_t nseg, uint32_t F, uint32_t xcd_log2, uint32_t* off, uint32_t* cursor) {
+    RJ_KLAUNCH(L, "scan_segments", k_scan_segments, nseg, PT_MAXF, hist, seg_off, nseg, F, xcd_log2, off,
                cursor);
 }
 

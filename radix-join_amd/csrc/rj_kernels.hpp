@@ -39,7 +39,7 @@ void launch_scan_bins(const Launch& L, const uint32_t* in, uint32_t n, uint32_t*
                       uint32_t* cursor);
 // per-segment scan: off[seg*F+d] = seg_off[seg] + prefix of hist[seg][0..d); off[nseg*F] = total
 void launch_scan_segments(const Launch& L, const uint32_t* hist, const uint32_t* seg_off,
-                          uint32_t nseg, uint32_t F, uint32_t* off, uint32_t* cursor);
+                          uint32_t nseg, uint32_t F, uint32_t xcd_log2, uint32_t* off, uint32_t* cursor);
 // grp_start[s] = sum_{t<s} ceil(len_t / group_tuples) over segments (seg_off[nseg+1])
 void launch_group_table(const Launch& L, const uint32_t* seg_off, uint32_t nseg,
                         uint32_t group_tuples, uint32_t* grp_start);

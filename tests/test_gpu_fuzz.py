@@ -148,6 +148,32 @@ def test_random_plan_forced_radix(seed, bits):
     assert pl.canonical_rows(got) == pl.canonical_rows(want)
 
 
+# ... and with the XCD-aware output placement of the big passes forced on (it normally starts at
+# 64 M tuples): per-XCD sub-ranges in the first pass, transposed grids in the later ones.
+@pytest.mark.parametrize("bits", [3, 11, 17, 20])
+@pytest.mark.parametrize("seed", range(_FIRST, _FIRST + min(_COUNT, 25)))
+def test_random_plan_forced_radix_xcd_placement(seed, bits):
+    p = random_plan(seed)
+    want = _oracle.execute(p)
+    if want.num_rows > 400_000:
+        pytest.skip("result too large to sort in a unit test")
+    old = os.environ.get("RJ_TUNE_XCD_MIN_ROWS")
+    os.environ["RJ_TUNE_XCD_MIN_ROWS"] = "0"  # read once, when the context is created
+    try:
+        c = capi.Context(radix_bits=bits)
+    finally:
+        if old is None:
+            del os.environ["RJ_TUNE_XCD_MIN_ROWS"]
+        else:
+            os.environ["RJ_TUNE_XCD_MIN_ROWS"] = old
+    try:
+        got = capi.execute(p, c)
+    finally:
+        c.destroy()
+    assert got.num_rows == want.num_rows
+    assert pl.canonical_rows(got) == pl.canonical_rows(want)
+
+
 # VARCHAR join keys (reference hash_join_omp<std::string>) in the mix: the same generator with
 # VARCHAR as the plan's key type most of the time; own seed range so that the plans above stay
 # what they were.  Also under a forced multi-pass radix plan (the 64-bit string hashes then go

@@ -15,9 +15,23 @@ pytestmark = pytest.mark.gpu
 NP_OF = {pl.INT32: np.int32, pl.INT64: np.int64, pl.FP64: np.float64}
 
 
-@pytest.fixture(scope="module")
-def ctx():
+# "xcd": the XCD-aware output placement of the big passes (per-XCD sub-ranges of every partition
+# in pass 1, grid transposition in the later passes; csrc/rj_device.hpp PassParams::xcd_log2 /
+# xcd_remap) normally starts at 64 M tuples — here it is forced for every pass, so these
+# 0.3-4 M-row joins (several tile groups per segment) run through it against the oracle.
+@pytest.fixture(scope="module", params=["default", "xcd"])
+def ctx(request):
+    import os
+
+    old = os.environ.get("RJ_TUNE_XCD_MIN_ROWS")
+    if request.param == "xcd":
+        os.environ["RJ_TUNE_XCD_MIN_ROWS"] = "0"  # read once, when the context is created
     c = capi.build_context()
+    if request.param == "xcd":
+        if old is None:
+            del os.environ["RJ_TUNE_XCD_MIN_ROWS"]
+        else:
+            os.environ["RJ_TUNE_XCD_MIN_ROWS"] = old
     yield c
     capi.destroy_context(c)
 
