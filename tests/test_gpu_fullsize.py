@@ -37,6 +37,30 @@ def run_and_verify(name):
         torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("name", ["config2", "config3"])
+def test_between_the_benchmarked_sizes_150m(name):
+    """150 M ⋈ 150 M of both benchmark shapes: 2^16 partitions — two plain-histogram passes of
+    2^8 (above the fine histogram's limit, below the 2^9-way passes of the 1 B runs), with the
+    XCD-aware output placement on (>= 64 M tuples) and, for the 12-byte tuples, the tagged join
+    table at 16 bits.  Closed-form verification as for the full sizes."""
+    import torch
+
+    ctx = capi.build_context()
+    try:
+        rel = wl.make_relations(name, torch.device("cuda"), rows=150_000_000)
+        R = wl.adopt(ctx, [rel.rk, rel.rp])
+        S = wl.adopt(ctx, [rel.sk, rel.sp])
+        res = ctx.execute_resident(wl.join_plan(rel.payload_type), [R, S])
+        digest = wl.verify_pk_fk(res, rel)
+        assert digest["rows"] == 150_000_000
+        res.free()
+        R.release()
+        S.release()
+    finally:
+        capi.destroy_context(ctx)
+        torch.cuda.empty_cache()
+
+
 def test_config2_100m_uniform_full_size():
     """BASELINE config 2: 100 M ⋈ 100 M INT32 uniform keys, INT32 payloads (fine histogram,
     packed {key, carry} pairs, two 2^7/2^8-way passes)"""
