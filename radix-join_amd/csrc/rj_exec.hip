@@ -381,24 +381,39 @@ class Exec {
         Words    cur = ws ? ws->w : Words{}, nxt = (P.aos3 && passes == 1) ? waos : wa;
         bool     cur_is_a = false;
         BufP       fine_off, fine_cursor, coarse_off, coarse_cursor;
+        // tiles per group of the first pass (the fine histogram must know it: see fine_xcd)
+        uint32_t tpg_first = tiles_per_group(n, 4096);
+        if (ctx->tune.tpg1 > 0) tpg_first = (uint32_t)ctx->tune.tpg1;
+        bool fine_xcd = false;
         if (fine) {
             const uint32_t NB = 1u << bits, F1 = 1u << pbits[0], F2 = 1u << pbits[1];
             BufP           fh = ctx->buf((uint64_t)NB * 4);
+            const uint64_t tiles = (n + PT_TILE - 1) / PT_TILE;
+            uint32_t       fgrid = (uint32_t)std::min<uint64_t>(tiles, (uint64_t)ctx->compute_units());
+            // XCD-aware placement of the first pass: per-sub-range counts out of the histogram
+            // (its grid then is a multiple of 8: workgroup w counts for sub-range w & 7)
+            fine_xcd = ctx->tune.xcd_split && n >= (uint64_t)ctx->tune.xcd_min_rows && fgrid >= 8;
+            if (fine_xcd) fgrid &= ~7u;
             fine_off = ctx->buf(((uint64_t)NB + 1) * 4);
             fine_cursor = ctx->buf((uint64_t)NB * 4);
             coarse_off = ctx->buf(((uint64_t)F1 + 1) * 4);
-            coarse_cursor = ctx->buf((uint64_t)F1 * 4);
+            coarse_cursor = ctx->buf((uint64_t)F1 * 4 * (fine_xcd ? 8 : 1));
+            BufP coarse_x;
             RJ_HIP(hipMemsetAsync(fh->p, 0, (uint64_t)NB * 4, ctx->stream));
-            const uint64_t tiles = (n + PT_TILE - 1) / PT_TILE;
-            const uint32_t fgrid = (uint32_t)std::min<uint64_t>(tiles, (uint64_t)ctx->compute_units());
+            if (fine_xcd) {
+                coarse_x = ctx->buf((uint64_t)F1 * 8 * 4);
+                RJ_HIP(hipMemsetAsync(coarse_x->p, 0, (uint64_t)F1 * 8 * 4, ctx->stream));
+            }
+            uint32_t* cx = fine_xcd ? coarse_x->as<uint32_t>() : nullptr;
             if (ws)
                 launch_fine_hist_words(L, ws->w, ws->packed, (uint32_t)n, shift0, pbits[0], pbits[1], fgrid,
-                                       fh->as<uint32_t>());
+                                       fh->as<uint32_t>(), fine_xcd ? tpg_first : 0u, cx);
             else
-                launch_fine_hist_src(L, src, KW, shift0, pbits[0], pbits[1], fgrid, fh->as<uint32_t>());
+                launch_fine_hist_src(L, src, KW, shift0, pbits[0], pbits[1], fgrid, fh->as<uint32_t>(),
+                                     fine_xcd ? tpg_first : 0u, cx);
             launch_scan_fine(L, fh->as<uint32_t>(), F1, F2, fine_off->as<uint32_t>(),
                              fine_cursor->as<uint32_t>(), coarse_off->as<uint32_t>(),
-                             coarse_cursor->as<uint32_t>());
+                             coarse_cursor->as<uint32_t>(), cx);
         }
         for (uint32_t p = 0; p < passes; ++p) {
             const uint32_t F = 1u << pbits[p];
@@ -411,8 +426,7 @@ class Exec {
             uint32_t n_groups;
             BufP     grp_start;
             if (p == 0) {
-                pp.tiles_per_group = tiles_per_group(n, 4096);
-                if (ctx->tune.tpg1 > 0) pp.tiles_per_group = (uint32_t)ctx->tune.tpg1;
+                pp.tiles_per_group = tpg_first;
                 uint64_t gt = (uint64_t)pp.tiles_per_group * PT_TILE;
                 n_groups = (uint32_t)((n + gt - 1) / gt);
             } else {
@@ -438,6 +452,7 @@ class Exec {
                     off = p == 0 ? coarse_off : fine_off;
                     cursor = p == 0 ? coarse_cursor : fine_cursor;
                     pp.cursor = cursor->as<uint32_t>();
+                    pp.xcd_log2 = (p == 0 && fine_xcd) ? 3u : 0u;
                 } else {
                     // sub-ranges per XCD only where a partition gets many runs (big inputs)
                     pp.xcd_log2 = (ctx->tune.xcd_split && p == 0 && n >= (uint64_t)ctx->tune.xcd_min_rows) ? 3u : 0u;

@@ -805,21 +805,41 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_hist(Loader ld, PassParams 
 // pass-1 offsets, and no second histogram pass over the partitioned tuples is needed.
 // Persistent workgroups (one per CU: the histogram takes most of the LDS) stride over the
 // tiles and flush their bins with one global add each.
+// xcd_tpg > 0 (XCD-aware placement, see PassParams::xcd_log2): the first pass' scatter works in
+// groups of xcd_tpg tiles and writes group g's runs into sub-range g & 7 of every partition, so
+// it needs the pass-1 digit counts per sub-range.  Workgroup w therefore counts exactly the tile
+// groups g with g & 7 == w & 7 (gridDim.x is a multiple of 8) — its whole LDS histogram belongs
+// to ONE sub-range, and the per-sub-range counts fall out of the flush (row sums of its bins)
+// with no extra work per tuple.
 template <class Loader>
 __global__ __launch_bounds__(PT_THREADS) void k_fine_hist(Loader ld, uint32_t n, uint32_t shift,
                                                           uint32_t b1, uint32_t b2,
-                                                          uint32_t* fine) {
+                                                          uint32_t* fine, uint32_t xcd_tpg,
+                                                          uint32_t* coarse_x) {
     __shared__ uint32_t s_f[1u << PT_FINEBITS];
     const uint32_t      NB = 1u << (b1 + b2), m1 = (1u << b1) - 1u, m2 = (1u << b2) - 1u;
     for (uint32_t d = threadIdx.x; d < NB; d += PT_THREADS) s_f[d] = 0;
     lds_barrier();
     const uint32_t tiles = (uint32_t)(((uint64_t)n + PT_TILE - 1) / PT_TILE);
+    // tile walk: plain striding, or the tile groups of this workgroup's sub-range
+    const uint32_t x = blockIdx.x & 7u, gstride = gridDim.x >> 3;
+    uint32_t       gk = blockIdx.x >> 3, gj = 0;  // group x + 8 * gk, tile gj inside it
+    auto           tile_of = [&](uint32_t k, uint32_t j) { return (x + 8u * k) * xcd_tpg + j; };
+    auto           advance = [&](uint32_t t) -> uint32_t {  // the tile after t, >= tiles: none
+        if (!xcd_tpg) return t + gridDim.x;
+        if (++gj < xcd_tpg && tile_of(gk, gj) < tiles) return tile_of(gk, gj);
+        gk += gstride;
+        gj = 0;
+        const uint64_t nt = (uint64_t)(x + 8ull * gk) * xcd_tpg;
+        return nt < tiles ? (uint32_t)nt : 0xffffffffu;
+    };
+    uint32_t t = xcd_tpg ? tile_of(gk, 0) : blockIdx.x;
     // Software pipeline: the LDS atomics of a tile (a third of its time) run while the NEXT
     // tile's loads are in flight — the raw loads are issued before the atomics, hashing (which
     // needs the data) comes after them.
     uint32_t lo[PT_ITEMS], hi[PT_ITEMS], raw = 0;
-    if (blockIdx.x < tiles) raw = ld.issue_keys(blockIdx.x * (uint32_t)PT_TILE, n, lo, hi);
-    for (uint32_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    if (t < tiles) raw = ld.issue_keys(t * (uint32_t)PT_TILE, n, lo, hi);
+    while (t < tiles) {
         const uint32_t ok = ld.finish_keys(t * (uint32_t)PT_TILE, n, raw, lo, hi);
         uint32_t       q[PT_ITEMS];
 #pragma unroll
@@ -827,16 +847,26 @@ __global__ __launch_bounds__(PT_THREADS) void k_fine_hist(Loader ld, uint32_t n,
             const uint32_t h = lo[j] >> shift;
             q[j] = ((h & m1) << b2) | ((h >> b1) & m2);
         }
-        const uint32_t t2 = t + gridDim.x;
+        const uint32_t t2 = advance(t);
         if (t2 < tiles) raw = ld.issue_keys(t2 * (uint32_t)PT_TILE, n, lo, hi);
 #pragma unroll
         for (int j = 0; j < PT_ITEMS; ++j)
             if ((ok >> j) & 1u) atomicAdd(&s_f[q[j]], 1u);
+        t = t2;
     }
     lds_barrier();
     for (uint32_t d = threadIdx.x; d < NB; d += PT_THREADS) {
         uint32_t c = s_f[d];
         if (c) atomicAdd(&fine[d], c);
+    }
+    if (xcd_tpg) {
+        const uint32_t F2 = 1u << b2;
+        for (uint32_t d1 = threadIdx.x; d1 <= m1; d1 += PT_THREADS) {
+            uint32_t sum = 0;
+            // (rotated start: the threads of a wave do not all hit the same LDS bank)
+            for (uint32_t i = 0; i < F2; ++i) sum += s_f[d1 * F2 + ((i + d1) & m2)];
+            if (sum) atomicAdd(&coarse_x[(d1 << 3) | x], sum);
+        }
     }
 }
 
@@ -847,7 +877,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_fine_hist(Loader ld, uint32_t n,
 __global__ __launch_bounds__(PT_MAXF) void k_scan_fine(const uint32_t* fine, uint32_t F1,
                                                        uint32_t F2, uint32_t* off2,
                                                        uint32_t* cursor2, uint32_t* off1,
-                                                       uint32_t* cursor1) {
+                                                       uint32_t* cursor1, const uint32_t* coarse_x) {
     __shared__ uint32_t s_wsum[PT_MAXF / 64];
     const uint32_t      d1 = blockIdx.x, below = d1 * F2;
     uint32_t            sum = 0;
@@ -871,7 +901,15 @@ __global__ __launch_bounds__(PT_MAXF) void k_scan_fine(const uint32_t* fine, uin
     }
     if (threadIdx.x == 0) {
         off1[d1] = base;
-        cursor1[d1] = base;
+        if (coarse_x) {  // eight sub-ranges (one per XCD) one behind the other: cursor1[d1 * 8 + x]
+            uint32_t at = base;
+            for (uint32_t x = 0; x < 8; ++x) {
+                cursor1[(d1 << 3) | x] = at;
+                at += coarse_x[(d1 << 3) | x];
+            }
+        } else {
+            cursor1[d1] = base;
+        }
         if (d1 + 1 == F1) {
             off1[F1] = base + tot;
             off2[(size_t)F1 * F2] = base + tot;
@@ -2106,34 +2144,40 @@ void launch_pass_hist_src(const Launch& L, const TupleSrc& src, int key_words, c
 }
 
 void launch_fine_hist_src(const Launch& L, const TupleSrc& src, int key_words, uint32_t shift,
-                          uint32_t b1, uint32_t b2, uint32_t grid, uint32_t* fine) {
+                          uint32_t b1, uint32_t b2, uint32_t grid, uint32_t* fine, uint32_t xcd_tpg,
+                          uint32_t* coarse_x) {
     if (!grid || !src.n_rows) return;
     if (key_words == 1) {
         SrcLoader<1, 0> ld{src};
         RJ_KLAUNCH(L, "pass1_hist", (k_fine_hist<SrcLoader<1, 0>>), grid, PT_THREADS, ld, src.n_rows,
-                   shift, b1, b2, fine);
+                   shift, b1, b2, fine, xcd_tpg, coarse_x);
     } else {
         SrcLoader<2, 0> ld{src};
         RJ_KLAUNCH(L, "pass1_hist", (k_fine_hist<SrcLoader<2, 0>>), grid, PT_THREADS, ld, src.n_rows,
-                   shift, b1, b2, fine);
+                   shift, b1, b2, fine, xcd_tpg, coarse_x);
     }
 }
 
 void launch_fine_hist_words(const Launch& L, const Words& in, bool packed, uint32_t n, uint32_t shift,
-                            uint32_t b1, uint32_t b2, uint32_t grid, uint32_t* fine) {
+                            uint32_t b1, uint32_t b2, uint32_t grid, uint32_t* fine, uint32_t xcd_tpg,
+                            uint32_t* coarse_x) {
     if (!grid || !n) return;
     if (packed) {
         PackedLoader ld{reinterpret_cast<const uint2*>(in.w[0])};
-        RJ_KLAUNCH(L, "pass1_hist", (k_fine_hist<PackedLoader>), grid, PT_THREADS, ld, n, shift, b1, b2, fine);
+        RJ_KLAUNCH(L, "pass1_hist", (k_fine_hist<PackedLoader>), grid, PT_THREADS, ld, n, shift, b1, b2, fine,
+                   xcd_tpg, coarse_x);
     } else {
         DenseLoader ld{in};
-        RJ_KLAUNCH(L, "pass1_hist", (k_fine_hist<DenseLoader>), grid, PT_THREADS, ld, n, shift, b1, b2, fine);
+        RJ_KLAUNCH(L, "pass1_hist", (k_fine_hist<DenseLoader>), grid, PT_THREADS, ld, n, shift, b1, b2, fine,
+                   xcd_tpg, coarse_x);
     }
 }
 
 void launch_scan_fine(const Launch& L, const uint32_t* fine, uint32_t F1, uint32_t F2,
-                      uint32_t* off2, uint32_t* cursor2, uint32_t* off1, uint32_t* cursor1) {
-    RJ_KLAUNCH(L, "scan_fine", k_scan_fine, F1, PT_MAXF, fine, F1, F2, off2, cursor2, off1, cursor1);
+                      uint32_t* off2, uint32_t* cursor2, uint32_t* off1, uint32_t* cursor1,
+                      const uint32_t* coarse_x) {
+    RJ_KLAUNCH(L, "scan_fine", k_scan_fine, F1, PT_MAXF, fine, F1, F2, off2, cursor2, off1, cursor1,
+               coarse_x);
 }
 
 template <int KW, int CW>

@@ -52,14 +52,20 @@ void launch_pass_hist_src(const Launch& L, const TupleSrc& src, int key_words, c
 // Fine histogram of a two-pass plan (both digits in one read of the source): fine[d1 * F2 + d2],
 // pre-zeroed; `grid` persistent workgroups (one per CU).  launch_scan_fine turns it into the
 // pass-2 offsets/cursors (off2[F1*F2 + 1], cursor2) and the pass-1 ones (off1[F1 + 1], cursor1).
+// xcd_tpg > 0 (grid a multiple of 8): XCD-aware placement of the first pass — workgroup w counts
+// the tile groups (of xcd_tpg tiles) g with g & 7 == w & 7 and also adds its pass-1 digit counts
+// to coarse_x[d1 * 8 + (w & 7)] (pre-zeroed); launch_scan_fine then writes cursor1[d1 * 8 + x]
 void launch_fine_hist_src(const Launch& L, const TupleSrc& src, int key_words, uint32_t shift,
-                          uint32_t b1, uint32_t b2, uint32_t grid, uint32_t* fine);
+                          uint32_t b1, uint32_t b2, uint32_t grid, uint32_t* fine, uint32_t xcd_tpg = 0,
+                          uint32_t* coarse_x = nullptr);
 // the same over tuples that already sit in the partition layout (hashed words / packed pairs):
 // the passes behind a sharded join's exchange
 void launch_fine_hist_words(const Launch& L, const Words& in, bool packed, uint32_t n, uint32_t shift,
-                            uint32_t b1, uint32_t b2, uint32_t grid, uint32_t* fine);
+                            uint32_t b1, uint32_t b2, uint32_t grid, uint32_t* fine, uint32_t xcd_tpg = 0,
+                            uint32_t* coarse_x = nullptr);
 void launch_scan_fine(const Launch& L, const uint32_t* fine, uint32_t F1, uint32_t F2,
-                      uint32_t* off2, uint32_t* cursor2, uint32_t* off1, uint32_t* cursor1);
+                      uint32_t* off2, uint32_t* cursor2, uint32_t* off1, uint32_t* cursor1,
+                      const uint32_t* coarse_x = nullptr);
 // aos3 (key_words == 1, carry_words == 2, last pass of a plan): out.w[0] receives 12-byte
 // {hashed key, carry lo, carry hi} tuples instead of a key array + a pair array
 void launch_pass_scatter_src(const Launch& L, const TupleSrc& src, int key_words, int carry_words,
