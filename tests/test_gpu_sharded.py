@@ -35,8 +35,22 @@ def combine(digests):
     return (n, s, x)
 
 
-def run_sharded(plan, n_ranks, **ctx_kw):
-    ctx = capi.Context(devices=[0] * n_ranks, **ctx_kw)
+def run_sharded(plan, n_ranks, xcd_placement=False, **ctx_kw):
+    import os
+
+    # xcd_placement: force the XCD-aware output placement of the big passes (normally from 64 M
+    # tuples) onto these small shards — stage A and the passes behind the exchange then run it
+    old = os.environ.get("RJ_TUNE_XCD_MIN_ROWS")
+    if xcd_placement:
+        os.environ["RJ_TUNE_XCD_MIN_ROWS"] = "0"  # read once, when the context is created
+    try:
+        ctx = capi.Context(devices=[0] * n_ranks, **ctx_kw)
+    finally:
+        if xcd_placement:
+            if old is None:
+                del os.environ["RJ_TUNE_XCD_MIN_ROWS"]
+            else:
+                os.environ["RJ_TUNE_XCD_MIN_ROWS"] = old
     tables = []
     try:
         assert ctx.n_devices == n_ranks
@@ -82,21 +96,23 @@ def join_plan(bt, pt, btypes, ptypes, outs, build_left=True):
     return p
 
 
+@pytest.mark.parametrize("xcd", [False, True])
 @pytest.mark.parametrize("n_ranks", [2, 4, 8])
-def test_baseline_shape_int32_payloads(n_ranks):
+def test_baseline_shape_int32_payloads(n_ranks, xcd):
     """config-2/4 shape: unique build keys, uniform probe keys, INT32 payloads (packed pairs:
     ONE array moves per relation)"""
     rng = np.random.default_rng(10 + n_ranks)
     nb, npr = 1_500_000, 2_500_000
     bt = pl.make_table([(pl.INT32, rng.permutation(nb).astype(np.int32)), (pl.INT32, np.arange(nb, dtype=np.int32))])
     pt = pl.make_table([(pl.INT32, rng.integers(0, nb + 100_000, npr).astype(np.int32)), (pl.INT32, np.arange(npr, dtype=np.int32))])
-    parts = check_against_oracle(join_plan(bt, pt, [pl.INT32, pl.INT32], [pl.INT32, pl.INT32], [(0, pl.INT32), (1, pl.INT32), (3, pl.INT32)]), n_ranks)
+    parts = check_against_oracle(join_plan(bt, pt, [pl.INT32, pl.INT32], [pl.INT32, pl.INT32], [(0, pl.INT32), (1, pl.INT32), (3, pl.INT32)]), n_ranks, xcd_placement=xcd)
     # every rank owns a share of the result (hash sharding balances uniform keys)
     assert all(p.num_rows > 0.5 * sum(q.num_rows for q in parts) / n_ranks for p in parts)
 
 
+@pytest.mark.parametrize("xcd", [False, True])
 @pytest.mark.parametrize("build_left", [True, False])
-def test_int64_payloads_null_keys_duplicates(build_left):
+def test_int64_payloads_null_keys_duplicates(build_left, xcd):
     """config-3 shape at small scale: INT64 payloads on both sides (12-byte tuples: a key array
     and a pair array move per relation), NULL keys on both sides, duplicate build keys, a hot
     probe key"""
@@ -111,7 +127,7 @@ def test_int64_payloads_null_keys_duplicates(build_left):
         outs = [(0, pl.INT32), (1, pl.INT64), (3, pl.INT64)]
     else:
         outs = [(3, pl.INT64), (0, pl.INT32), (1, pl.INT64)]
-    check_against_oracle(join_plan(bt, pt, [pl.INT32, pl.INT64], [pl.INT32, pl.INT64], outs, build_left), 4)
+    check_against_oracle(join_plan(bt, pt, [pl.INT32, pl.INT64], [pl.INT32, pl.INT64], outs, build_left), 4, xcd_placement=xcd)
 
 
 def test_int64_keys_and_key_only_outputs():
