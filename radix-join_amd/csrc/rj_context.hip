@@ -24,6 +24,7 @@ void Tuning::from_env() {
     tpg1 = env_int("RJ_TUNE_TPG1", tpg1);
     xcd_split = env_int("RJ_TUNE_XCD_SPLIT", xcd_split);
     tpg2 = env_int("RJ_TUNE_TPG2", tpg2);
+    packed_side = env_int("RJ_TUNE_PACKED_SIDE", packed_side);
     xcd_min_rows = env_int("RJ_TUNE_XCD_MIN_ROWS", xcd_min_rows);
     bcast = env_int("RJ_TUNE_BCAST", bcast);
     diag = env_int("RJ_DIAG", diag);

@@ -356,9 +356,17 @@ class Exec {
         if (aos_mid) {
             for (uint32_t k = 0; k < std::min<uint32_t>(passes - 1, 2); ++k) {
                 MID[k] = ctx->buf(std::max<uint64_t>(n, 1) * 12);
-                if (!fine) SIDE[k] = ctx->buf(std::max<uint64_t>(n, 1) * 2);
+                if (!fine) SIDE[k] = ctx->buf(std::max<uint64_t>(n, 1) * 2 + 16);
             }
         }
+        // packed pairs above the fine histogram's limit: a later pass' histogram would read the
+        // 8-byte pairs for their 4-byte keys — the pass before it writes the NEXT digit of every
+        // tuple as a 16-bit side array instead (2 bytes written + 2 read per tuple instead of 8 read)
+        const bool packed_side = P.packed && !fine && passes >= 2 && ctx->tune.packed_side != 0 &&
+                                 n >= (uint64_t)ctx->tune.xcd_min_rows;
+        if (packed_side)
+            for (uint32_t k = 0; k < std::min<uint32_t>(passes - 1, 2); ++k)
+                SIDE[k] = ctx->buf(std::max<uint64_t>(n, 1) * 2 + 16);
         for (int a = 0; a < (P.packed ? 1 : P.NW); ++a) {
             // a two-word carry is ONE array of 8-byte pairs (at word KW), key + one carry word
             // one array of pairs altogether (packed)
@@ -464,7 +472,7 @@ class Exec {
                     pp.cursor = cursor->as<uint32_t>();
                     if (p == 0 && !ws)
                         launch_pass_hist_src(L, src, KW, pp, n_groups);
-                    else if (aos_mid && p > 0)
+                    else if ((aos_mid || packed_side) && p > 0)
                         launch_pass_hist_digits(L, SIDE[(p - 1) % 2]->as<uint16_t>(), pp, n_groups);
                     else if (P.packed)
                         launch_pass_hist_packed(L, cur.w[0], pp, n_groups);
@@ -491,6 +499,11 @@ class Exec {
                         launch_pass_scatter_aos3(L, MID[(p - 1) % 2]->as<uint32_t>(), pp, n_groups, o.w[0]);
                     nxt = o;
                 } else if (P.packed) {
+                    if (packed_side && p + 1 < passes) {
+                        pp.side_out = SIDE[p % 2]->as<uint16_t>();
+                        pp.next_shift = shift + pbits[p];
+                        pp.next_mask = (1u << pbits[p + 1]) - 1u;
+                    }
                     if (p == 0 && !ws)
                         launch_pass_scatter_src_packed(L, src, pp, n_groups, nxt.w[0]);
                     else

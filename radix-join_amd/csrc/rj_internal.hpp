@@ -176,6 +176,7 @@ struct Tuning {
     int aos_mid = 2;      // RJ_TUNE_AOS_MID: ... and so do the passes before it (+ a 16-bit digit side array
                           // for the next histogram); 0: key array + pair array between the passes
     int tpg1 = 0;         // RJ_TUNE_TPG1: tiles per group of pass 1 (0 = auto)
+    int packed_side = 0;  // RJ_TUNE_PACKED_SIDE: digit side array between the passes of packed plans
     int tpg2 = 0;         // RJ_TUNE_TPG2: tiles per group of the later passes (0 = auto)
     int xcd_min_rows = 64 << 20;  // RJ_TUNE_XCD_MIN_ROWS: ... for passes over at least this many tuples
     int xcd_split = 1;    // RJ_TUNE_XCD_SPLIT: XCD-aware output placement of the big passes (PassParams::xcd_log2, xcd_remap)

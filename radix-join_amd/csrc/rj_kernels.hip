@@ -472,17 +472,52 @@ struct Aos3Loader {
 // of that successor reads 2 bytes per tuple.  key_tile hands the digit back in the bit position
 // the histogram kernel takes it from.
 struct DigitLoader {
+    static constexpr bool kNeedsBegin = true;
     const uint16_t* digits;
     uint32_t        shift;
-    __device__ __forceinline__ uint32_t key_tile(uint32_t base, uint32_t end, uint32_t (&hk)[PT_ITEMS]) const {
-        uint32_t ok = 0;
+    // Full tiles read sixteen consecutive digits per thread with two 16-byte loads.  Loads are
+    // 4-byte aligned, digits 2-byte: a full tile that starts at an ODD index covers the window
+    // one element earlier, [base - 1, base - 1 + PT_TILE).  The windows of consecutive tiles
+    // still tile the group's range [begin, end) exactly once (the histogram does not care which
+    // tile counts a tuple):
+    //   * the element in front of the group's first tile (begin - 1) is masked out;
+    //   * the element a full odd tile leaves behind (base + PT_TILE - 1) is the first one of the
+    //     next tile's window — a partial last tile starts one element early for it, and when
+    //     there is no next tile extra() hands it to thread 0.
+    __device__ __forceinline__ uint32_t key_tile(uint32_t base, uint32_t begin, uint32_t end,
+                                                 uint32_t (&hk)[PT_ITEMS]) const {
+        static_assert(PT_ITEMS == 16, "two 16-byte loads of eight digits each");
+        if (base + PT_TILE <= end) {
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(digits) + (base >> 1);
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const uint32_t wi = (v * PT_THREADS + threadIdx.x) * 4;
+                const u32x4a   x = __builtin_nontemporal_load(reinterpret_cast<const u32x4a*>(w + wi));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    hk[8 * v + 2 * e] = (x[e] & 0xffffu) << shift;
+                    hk[8 * v + 2 * e + 1] = (x[e] >> 16) << shift;
+                }
+            }
+            uint32_t ok = PT_ALL_ITEMS;
+            if ((base & 1u) && base == begin && threadIdx.x == 0) ok &= ~1u;  // element begin - 1
+            return ok;
+        }
+        const uint32_t b0 = ((base & 1u) && base != begin) ? base - 1u : base;
+        uint32_t       ok = 0;
 #pragma unroll
         for (int j = 0; j < PT_ITEMS; ++j) {
-            const uint32_t i = base + j * PT_THREADS + threadIdx.x;
+            const uint32_t i = b0 + j * PT_THREADS + threadIdx.x;
             hk[j] = (uint32_t)digits[min(i, end - 1u)] << shift;
             ok |= (uint32_t)(i < end) << j;
         }
         return ok;
+    }
+    // the group's last element when its last tile is a full odd one (see above)
+    __device__ __forceinline__ bool extra(uint32_t begin, uint32_t end, uint32_t& hk) const {
+        if (threadIdx.x != 0 || !(begin & 1u) || end == begin || (end - begin) % (uint32_t)PT_TILE) return false;
+        hk = (uint32_t)digits[end - 1u] << shift;
+        return true;
     }
 };
 
@@ -773,6 +808,11 @@ __device__ __forceinline__ bool group_range(const PassParams& pp, uint32_t g, ui
     return begin < end;
 }
 
+template <class L, class = void>
+struct loader_needs_begin : std::false_type {};
+template <class L>
+struct loader_needs_begin<L, std::enable_if_t<L::kNeedsBegin>> : std::true_type {};
+
 // ============================================================== K2 histogram
 // Counting half of the radix partition (reference counterpart: the serial
 // histogram src/execute.cpp:124-132).  LDS atomics per tuple, F global adds per group for
@@ -787,10 +827,18 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_hist(Loader ld, PassParams 
     lds_barrier();
     for (uint32_t base = begin; base < end; base += PT_TILE) {
         uint32_t hk[PT_ITEMS];
-        uint32_t ok = ld.key_tile(base, end, hk);
+        uint32_t ok;
+        if constexpr (loader_needs_begin<Loader>::value)
+            ok = ld.key_tile(base, begin, end, hk);
+        else
+            ok = ld.key_tile(base, end, hk);
 #pragma unroll
         for (int j = 0; j < PT_ITEMS; ++j)
             if ((ok >> j) & 1u) atomicAdd(&s_h[(hk[j] >> pp.shift) & mask], 1u);
+    }
+    if constexpr (loader_needs_begin<Loader>::value) {
+        uint32_t hx;
+        if (ld.extra(begin, end, hx)) atomicAdd(&s_h[(hx >> pp.shift) & mask], 1u);
     }
     lds_barrier();
     for (uint32_t d = threadIdx.x; d < F; d += PT_THREADS) {
@@ -1141,8 +1189,10 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter_packed(Loader ld, P
         for (int k = 0; k < PT_ITEMS; ++k) {
             const uint32_t i = k * PT_THREADS + threadIdx.x;
             if (i < total) {
-                const uint2 v = s_stage[i];
-                out[s_delta[(v.x >> pp.shift) & mask] + i] = v;
+                const uint2    v = s_stage[i];
+                const uint32_t g = s_delta[(v.x >> pp.shift) & mask] + i;
+                out[g] = v;
+                if (pp.side_out) pp.side_out[g] = (uint16_t)((v.x >> pp.next_shift) & pp.next_mask);
             }
         }
         // no barrier: the next tile passes two barriers before it overwrites s_stage / s_delta

@@ -37,15 +37,30 @@ def run_and_verify(name):
         torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("side_arrays", [False, True])
 @pytest.mark.parametrize("name", ["config2", "config3"])
-def test_between_the_benchmarked_sizes_150m(name):
+def test_between_the_benchmarked_sizes_150m(name, side_arrays):
     """150 M ⋈ 150 M of both benchmark shapes: 2^16 partitions — two plain-histogram passes of
     2^8 (above the fine histogram's limit, below the 2^9-way passes of the 1 B runs), with the
     XCD-aware output placement on (>= 64 M tuples) and, for the 12-byte tuples, the tagged join
-    table at 16 bits.  Closed-form verification as for the full sizes."""
+    table at 16 bits.  side_arrays: the optional digit side arrays between the passes
+    (RJ_TUNE_PACKED_SIDE / RJ_TUNE_AOS_MID = 1; net-neutral, off by default) — the second pass'
+    histogram then reads 16-bit digits.  Closed-form verification as for the full sizes."""
+    import os
+
     import torch
 
-    ctx = capi.build_context()
+    env = {"RJ_TUNE_PACKED_SIDE": "1", "RJ_TUNE_AOS_MID": "1"} if side_arrays else {}
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)  # read once, when the context is created
+    try:
+        ctx = capi.build_context()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
     try:
         rel = wl.make_relations(name, torch.device("cuda"), rows=150_000_000)
         R = wl.adopt(ctx, [rel.rk, rel.rp])

@@ -19,19 +19,32 @@ NP_OF = {pl.INT32: np.int32, pl.INT64: np.int64, pl.FP64: np.float64}
 # in pass 1, grid transposition in the later passes; csrc/rj_device.hpp PassParams::xcd_log2 /
 # xcd_remap) normally starts at 64 M tuples — here it is forced for every pass, so these
 # 0.3-4 M-row joins (several tile groups per segment) run through it against the oracle.
-@pytest.fixture(scope="module", params=["default", "xcd"])
+# "side": on top of that, 16 forced radix bits (two plain-histogram passes) with the digit side
+# arrays between the passes switched on (RJ_TUNE_AOS_MID=1 for 12-byte tuples, RJ_TUNE_PACKED_SIDE=1
+# for packed pairs; both measured net-neutral and off by default): the later pass' histogram then
+# reads 16-bit digits with the vector loader, full tiles at odd offsets included.
+_KNOBS = {
+    "default": ({}, {}),
+    "xcd": ({"RJ_TUNE_XCD_MIN_ROWS": "0"}, {}),
+    "side": ({"RJ_TUNE_XCD_MIN_ROWS": "0", "RJ_TUNE_AOS_MID": "1", "RJ_TUNE_PACKED_SIDE": "1"}, {"radix_bits": 16}),
+}
+
+
+@pytest.fixture(scope="module", params=list(_KNOBS))
 def ctx(request):
     import os
 
-    old = os.environ.get("RJ_TUNE_XCD_MIN_ROWS")
-    if request.param == "xcd":
-        os.environ["RJ_TUNE_XCD_MIN_ROWS"] = "0"  # read once, when the context is created
-    c = capi.build_context()
-    if request.param == "xcd":
-        if old is None:
-            del os.environ["RJ_TUNE_XCD_MIN_ROWS"]
-        else:
-            os.environ["RJ_TUNE_XCD_MIN_ROWS"] = old
+    env, kw = _KNOBS[request.param]
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)  # read once, when the context is created
+    try:
+        c = capi.Context(**kw)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
     yield c
     capi.destroy_context(c)
 
