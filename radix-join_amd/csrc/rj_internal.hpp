@@ -178,7 +178,7 @@ struct Tuning {
     int tpg1 = 0;         // RJ_TUNE_TPG1: tiles per group of pass 1 (0 = auto)
     int packed_side = 0;  // RJ_TUNE_PACKED_SIDE: digit side array between the passes of packed plans
     int tpg2 = 0;         // RJ_TUNE_TPG2: tiles per group of the later passes (0 = auto)
-    int xcd_min_rows = 64 << 20;  // RJ_TUNE_XCD_MIN_ROWS: ... for passes over at least this many tuples
+    int xcd_min_rows = 40 << 20;  // RJ_TUNE_XCD_MIN_ROWS: ... for passes over at least this many tuples
     int xcd_split = 1;    // RJ_TUNE_XCD_SPLIT: XCD-aware output placement of the big passes (PassParams::xcd_log2, xcd_remap)
     int bcast = 1;        // RJ_TUNE_BCAST: broadcast join for build sides that fit one LDS table
     int diag = 0;         // RJ_DIAG: 1 = join phase stamps, 2 = host-side timings on stderr

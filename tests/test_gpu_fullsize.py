@@ -42,7 +42,7 @@ def run_and_verify(name):
 def test_between_the_benchmarked_sizes_150m(name, side_arrays):
     """150 M ⋈ 150 M of both benchmark shapes: 2^16 partitions — two plain-histogram passes of
     2^8 (above the fine histogram's limit, below the 2^9-way passes of the 1 B runs), with the
-    XCD-aware output placement on (>= 64 M tuples) and, for the 12-byte tuples, the tagged join
+    XCD-aware output placement on (>= 40 Mi tuples) and, for the 12-byte tuples, the tagged join
     table at 16 bits.  side_arrays: the optional digit side arrays between the passes
     (RJ_TUNE_PACKED_SIDE / RJ_TUNE_AOS_MID = 1; net-neutral, off by default) — the second pass'
     histogram then reads 16-bit digits.  Closed-form verification as for the full sizes."""

@@ -149,7 +149,7 @@ def test_random_plan_forced_radix(seed, bits):
 
 
 # ... and with the XCD-aware output placement of the big passes forced on (it normally starts at
-# 64 M tuples): per-XCD sub-ranges in the first pass, transposed grids in the later ones.
+# 40 Mi tuples): per-XCD sub-ranges in the first pass, transposed grids in the later ones.
 @pytest.mark.parametrize("bits", [3, 11, 17, 20])
 @pytest.mark.parametrize("seed", range(_FIRST, _FIRST + min(_COUNT, 25)))
 def test_random_plan_forced_radix_xcd_placement(seed, bits):

@@ -17,7 +17,7 @@ NP_OF = {pl.INT32: np.int32, pl.INT64: np.int64, pl.FP64: np.float64}
 
 # "xcd": the XCD-aware output placement of the big passes (per-XCD sub-ranges of every partition
 # in pass 1, grid transposition in the later passes; csrc/rj_device.hpp PassParams::xcd_log2 /
-# xcd_remap) normally starts at 64 M tuples — here it is forced for every pass, so these
+# xcd_remap) normally starts at 40 Mi tuples — here it is forced for every pass, so these
 # 0.3-4 M-row joins (several tile groups per segment) run through it against the oracle.
 # "side": on top of that, 16 forced radix bits (two plain-histogram passes) with the digit side
 # arrays between the passes switched on (RJ_TUNE_AOS_MID=1 for 12-byte tuples, RJ_TUNE_PACKED_SIDE=1

@@ -38,7 +38,7 @@ def combine(digests):
 def run_sharded(plan, n_ranks, xcd_placement=False, **ctx_kw):
     import os
 
-    # xcd_placement: force the XCD-aware output placement of the big passes (normally from 64 M
+    # xcd_placement: force the XCD-aware output placement of the big passes (normally from 40 Mi
     # tuples) onto these small shards — stage A and the passes behind the exchange then run it
     old = os.environ.get("RJ_TUNE_XCD_MIN_ROWS")
     if xcd_placement:
