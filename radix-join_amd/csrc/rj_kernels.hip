@@ -486,11 +486,11 @@ struct DigitLoader {
     //     there is no next tile extra() hands it to thread 0.
     __device__ __forceinline__ uint32_t key_tile(uint32_t base, uint32_t begin, uint32_t end,
                                                  uint32_t (&hk)[PT_ITEMS]) const {
-        static_assert(PT_ITEMS == 16, "two 16-byte loads of eight digits each");
+        static_assert(PT_ITEMS % 8 == 0, "16-byte loads of eight digits each");
         if (base + PT_TILE <= end) {
             const uint32_t* w = reinterpret_cast<const uint32_t*>(digits) + (base >> 1);
 #pragma unroll
-            for (int v = 0; v < 2; ++v) {
+            for (int v = 0; v < PT_ITEMS / 8; ++v) {
                 const uint32_t wi = (v * PT_THREADS + threadIdx.x) * 4;
                 const u32x4a   x = __builtin_nontemporal_load(reinterpret_cast<const u32x4a*>(w + wi));
 #pragma unroll
