@@ -2064,6 +2064,14 @@ __global__ __launch_bounds__(256) void k_finish_streams(FinishStreams fs,
         for (uint32_t k = lane; k < nb / 4; k += 64) reinterpret_cast<uint32_t*>(bm)[k] = 0xffffffffu;
         return;
     }
+    if (nr == rf && rf == ROWS64) {
+        // full INT64 / FP64 page: 1007 bits = 126 bytes from offset 8066 — one halfword, then 31
+        // dwords (the last byte holds 7 bits)
+        static_assert(ROWS64 == 1007 && ((PAGE_BYTES - 126 + 2) & 3u) == 0, "bitmap layout of a full 8-byte page");
+        if (lane == 0) *reinterpret_cast<uint16_t*>(bm) = 0xffffu;
+        if (lane < 31) reinterpret_cast<uint32_t*>(bm + 2)[lane] = lane == 30 ? 0x7fffffffu : 0xffffffffu;
+        return;
+    }
     for (uint32_t k = lane; k < nb; k += 64) {
         uint32_t bits = nr - k * 8u;
         bm[k] = bits >= 8 ? 0xff : (uint8_t)((1u << bits) - 1u);
