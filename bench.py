@@ -104,6 +104,16 @@ def roofline(stats, rows_build, rows_probe, steps_profiled, payload_bytes, workl
     # dominant = longest average launch (ties by name: deterministic)
     dom = max(sorted(kernels), key=lambda n: kernels[n]["avg_launch_ms"])
     d = kernels[dom]
+    # the north-star bar as SURVEY.md §8(d) defines it: the probe phase's READ bytes (partitioned S
+    # tuple + partitioned R tuple per probe tuple) over the build/probe kernel's time, against the
+    # 8 TB/s spec — the kernel also writes the materialised output in that time, so this is below
+    # `frac` (all bytes) by construction
+    probe_read = None
+    if "join_build_probe" in kernels:
+        j = kernels["join_build_probe"]
+        rd = 2 * (4.0 + payload_bytes) * rows_probe
+        probe_read = {"read_bytes_per_launch": rd, "achieved": rd / (j["avg_launch_ms"] * 1e-3) / 1e9,
+                      "frac": rd / (j["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
     return {
         "kernel": dom,
         "bound": "hbm",
@@ -113,6 +123,11 @@ def roofline(stats, rows_build, rows_probe, steps_profiled, payload_bytes, workl
         "frac": d["frac"],
         "traffic": d["traffic"],
         "traffic_source": (traffic_all.get("source") if d["traffic"] else None),
+        # `traffic` replays the PMC passes committed under profiles/ (counters cannot be collected
+        # inside a timed run); `achieved` and the kernel times ARE measured in this run
+        "traffic_measured_in_run": False,
+        "probe_read_frac": probe_read["frac"] if probe_read else None,
+        "probe_read": probe_read,
         "avg_launch_ms": d["avg_launch_ms"],
         "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
         "min_frac_kernel": min(sorted(kernels), key=lambda n: kernels[n]["frac"]),
@@ -193,8 +208,13 @@ def job_plan_ms(dev_index, queries=("1a", "13d", "10c"), repeat=3):
     fx = job.load_fixture()
     rng = np.random.default_rng(7)
     cache = {}
-    ctx = capi.Context(device=dev_index)
-    out = {}
+    # what Contest::build_context() does (RJ_CTX_PREWARM): the one-off set-up costs land in the
+    # context's construction, which the harness times once (tests/read_sql.cpp:1279-1283), not in
+    # the first query
+    t0 = time.perf_counter()
+    ctx = capi.Context(device=dev_index, prewarm=True)
+    build_context_ms = (time.perf_counter() - t0) * 1e3
+    out = {"build_context_ms": build_context_ms}
     for name in queries:
         q = fx["queries"][name]
         tables = job.make_scaled_inputs(q, fx["schema"], rng, cache)

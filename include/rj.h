@@ -127,11 +127,20 @@ typedef struct rj_config {
     int32_t  rank_base;   /* global rank of the first local device (local device i = rank_base+i) */
     const rj_comm_id* comm_id;  /* required when world_size > local devices                  */
     int32_t  exchange;    /* RJ_EXCHANGE_*                                                     */
-    int32_t  reserved0;
+    int32_t  flags;       /* RJ_CTX_*                                                          */
 } rj_config;
 
+/* rj_config.flags.  RJ_CTX_PREWARM: pay the one-off costs of the first rj_execute inside
+ * rj_context_create instead — pinned staging for uploads and result copies, the upload stream,
+ * the host worker threads, the code objects of the kernels (HIP loads them at first launch).
+ * Contest::build_context() sets it: the harness times build_context once
+ * (reference tests/read_sql.cpp:1279-1283) and execute once per query (:1234-1236), so set-up
+ * cost belongs there, not into the first query.                                              */
+enum { RJ_CTX_PREWARM = 1 };
+
 int         rj_context_create(rj_context** out, const rj_config* cfg /* may be NULL */);
-void        rj_context_destroy(rj_context* ctx);
+void        rj_context_destroy(rj_context* ctx); /* a handle from rj_context_device() is owned by
+                                                     its group context: destroying it is a no-op */
 const char* rj_last_error(const rj_context* ctx); /* ctx may be NULL: last create error */
 int         rj_abi_version(void);
 /* Local devices of a context and the per-device context of each (owned by `ctx`; valid for all
@@ -179,8 +188,11 @@ uint64_t rj_result_col_pages(const rj_result* r, uint64_t col);
 /* Copy column `col` into caller-allocated pages (dst[i] = 8192-byte block,
  * e.g. `new Page` so that Column::~Column, plan.h:95-99, can delete them).   */
 int      rj_result_copy_pages(rj_result* r, uint64_t col, void* const* dst, uint64_t n_dst);
-/* Device pointer to the contiguous page images of a fixed-width column
- * (valid until rj_result_free); NULL for VARCHAR columns.                    */
+/* Device pointer to the contiguous page images of a column whose pages sit in HBM (valid until
+ * rj_result_free): fixed-width columns, and VARCHAR columns of large results, which are encoded
+ * on the device.  NULL for host-encoded VARCHAR columns and for a result gathered from several
+ * devices (rj_execute on a multi-device context: its pages are not one run — use
+ * rj_result_copy_pages).                                                     */
 const void* rj_result_device_pages(const rj_result* r, uint64_t col);
 void     rj_result_free(rj_result* r);
 
@@ -203,6 +215,24 @@ int rj_execute_sharded(rj_context* ctx, const rj_plan* plan, rj_table* const* ta
  * with the reason in `why` (optional, NUL-terminated, at most why_cap bytes).  Looks at the plan
  * only: needs neither a context nor a GPU.                                                    */
 int rj_plan_shardable(const rj_plan* plan, char* why, size_t why_cap);
+
+/* The layout of the exchange step, as a pure function of the all-gathered count tensor (host
+ * arithmetic only: needs neither a context nor a GPU; this is what the library itself runs between
+ * the count all-gather and the all-to-all, exposed so that it can be checked — and rehearsed over
+ * any transport, e.g. gloo on CPUs — without one).  Stage A of a sharded join partitions a rank's
+ * tuples by (owner rank, first local radix digit) and lays them out owner-major;
+ *   counts[(src * world + dst) * subs + sub] = tuples rank `src` holds for owner `dst`, digit `sub`.
+ * For rank `rank` (all outputs optional, in TUPLES): send_off/send_cnt[world] = the slice of its
+ * stage-A output that goes to each rank; recv_off/recv_cnt[world] = where each source's slice
+ * lands in its receive buffer; seg_begin/seg_end[subs * world] = the runs that arrive, listed
+ * digit-major (run of digit k from source s at index k * world + s) — the input segments of the
+ * next radix pass, `world` of them feeding first-level partition k; part_off[subs + 1] = prefix of
+ * those partitions' sizes; n_recv = tuples received.  RJ_ERR_UNSUPPORTED when ANY rank of the
+ * world would receive more than 2^32 - 16 tuples (every rank takes that decision alike, before a
+ * collective moves data); message in rj_last_error(NULL).                                       */
+int rj_exchange_plan(uint32_t world, uint32_t subs, uint32_t rank, const uint64_t* counts,
+                     uint64_t* send_off, uint64_t* send_cnt, uint64_t* recv_off, uint64_t* recv_cnt,
+                     uint32_t* seg_begin, uint32_t* seg_end, uint32_t* part_off, uint64_t* n_recv);
 
 /* Lower-level pieces of the same path, for callers that run the exchange themselves (e.g.
  * torch.distributed in pyrj.dist, gloo on CPU in the tests).  Tuples are SoA: `key` (int32)

@@ -5,6 +5,7 @@
 #include <mutex>
 
 #include "rj_internal.hpp"
+#include "rj_xplan.hpp"
 
 using namespace rj;
 
@@ -30,7 +31,7 @@ static int guarded(rj_context* ctx, F&& f) {
 
 extern "C" {
 
-int rj_abi_version(void) { return 2; }
+int rj_abi_version(void) { return 3; }
 
 int rj_context_create(rj_context** out, const rj_config* cfg) {
     if (!out) return RJ_ERR_ARG;
@@ -85,8 +86,10 @@ int rj_context_create(rj_context** out, const rj_config* cfg) {
             std::vector<Context*> lanes;
             for (int i = 0; i < c->n_lanes(); ++i) lanes.push_back(c->lane(i));
             c->comm.reset(new Comm(lanes, world, cfg ? cfg->rank_base : 0, cfg ? cfg->exchange : 0,
-                                   cfg ? cfg->comm_id : nullptr));
+                                   cfg ? cfg->comm_id : nullptr, c->tune.exchange_timeout_ms));
         }
+        if (cfg && (cfg->flags & RJ_CTX_PREWARM))
+            for (int i = 0; i < c->n_lanes(); ++i) c->lane(i)->prewarm();
         RJ_HIP(hipSetDevice(devs[0]));
         *out = c.release();
     } catch (const rj::Error& e) {
@@ -105,6 +108,12 @@ int rj_context_create(rj_context** out, const rj_config* cfg) {
 
 void rj_context_destroy(rj_context* ctx) {
     if (!ctx) return;
+    // a per-device handle (rj_context_device) belongs to its group context: destroying it here
+    // would free it a second time when the group goes (and lane 0 IS the group)
+    if (ctx->group) {
+        ctx->last_error = "rj_context_destroy: this is a per-device handle owned by its group context (ignored)";
+        return;
+    }
     delete ctx;
 }
 
@@ -271,6 +280,9 @@ int rj_result_copy_pages(rj_result* r, uint64_t col, void* const* dst, uint64_t 
 
 const void* rj_result_device_pages(const rj_result* r, uint64_t c) {
     if (!r || c >= r->cols.size() || !r->cols[c].dev_pages) return nullptr;
+    // a column gathered from several devices is not one contiguous run of rj_result_col_pages()
+    // pages: fetch it with rj_result_copy_pages
+    if (!r->cols[c].more.empty()) return nullptr;
     return r->cols[c].dev_pages->p;
 }
 
@@ -304,6 +316,36 @@ int rj_plan_shardable(const rj_plan* plan, char* why, size_t why_cap) {
         why[why_cap - 1] = 0;
     }
     return ok ? 1 : 0;
+}
+
+int rj_exchange_plan(uint32_t world, uint32_t subs, uint32_t rank, const uint64_t* counts, uint64_t* send_off,
+                     uint64_t* send_cnt, uint64_t* recv_off, uint64_t* recv_cnt, uint32_t* seg_begin,
+                     uint32_t* seg_end, uint32_t* part_off, uint64_t* n_recv) {
+    if (!counts) return RJ_ERR_ARG;
+    try {
+        ExchangePlan p;
+        exchange_plan(world, subs, rank, counts, p);
+        auto put = [](auto* dst, const auto& v) {
+            if (dst) std::copy(v.begin(), v.end(), dst);
+        };
+        put(send_off, p.send_off);
+        put(send_cnt, p.send_cnt);
+        put(recv_off, p.recv_off);
+        put(recv_cnt, p.recv_cnt);
+        put(seg_begin, p.seg_begin);
+        put(seg_end, p.seg_end);
+        put(part_off, p.part_off);
+        if (n_recv) *n_recv = p.n_recv;
+        return RJ_OK;
+    } catch (const rj::Error& e) {
+        std::lock_guard<std::mutex> g(g_err_mu);
+        g_create_error = e.what();  // rj_last_error(NULL)
+        return e.code;
+    } catch (const std::exception& e) {
+        std::lock_guard<std::mutex> g(g_err_mu);
+        g_create_error = e.what();
+        return RJ_ERR_DEVICE;
+    }
 }
 
 int rj_shard_partition(rj_context* ctx, const rj_table* t, uint64_t key_col, uint64_t carry_col,

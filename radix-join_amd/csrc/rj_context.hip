@@ -31,6 +31,11 @@ void Tuning::from_env() {
     varchar_dev_rows = env_int("RJ_TUNE_VARCHAR_DEV", varchar_dev_rows);
     vkey_hash_bits = env_int("RJ_DEBUG_VKEY_HASH_BITS", vkey_hash_bits);
     sync_upload = env_int("RJ_SYNC_UPLOAD", sync_upload);
+    wide_carry = env_int("RJ_TUNE_WIDE_CARRY", wide_carry);
+    fold_owner = env_int("RJ_TUNE_FOLD_OWNER", fold_owner);
+    exchange_timeout_ms = env_int("RJ_EXCHANGE_TIMEOUT_MS", exchange_timeout_ms);
+    debug_shard_fail = env_int("RJ_DEBUG_SHARD_FAIL", debug_shard_fail);
+    debug_shard_fail_rank = env_int("RJ_DEBUG_SHARD_FAIL_RANK", debug_shard_fail_rank);
 }
 
 // ---------------------------------------------------------------- DevPool --
@@ -196,6 +201,27 @@ int Context::compute_units() {
         n_cu = v > 0 ? v : 256;
     }
     return n_cu;
+}
+
+// What the first rj_execute of a fresh context would otherwise pay (job/1a: 44 ms against 1.4 ms
+// for the calls after it): pinned staging in both directions, the upload stream, the host worker
+// threads, and the code objects of the kernels, which HIP loads when a kernel of a translation
+// unit is first launched.
+void Context::prewarm() {
+    RJ_HIP(hipSetDevice(device));
+    constexpr size_t STAGE = (size_t)2 * 4096 * PAGE_BYTES;  // rj_table.hip: two 32 MiB halves
+    (void)staging(STAGE);
+    (void)upload_staging(STAGE);
+    (void)small_pinned();
+    (void)upload_stream();
+    (void)compute_units();
+    parallel_for(4096, 1, [](size_t, size_t) {});  // spins up the host pool
+    BufP         b = buf(256);
+    const Launch L = launch();
+    RJ_HIP(hipMemsetAsync(b->p, 0, 256, stream));
+    launch_scan_bins(L, b->as<uint32_t>(), 1, b->as<uint32_t>() + 8, nullptr);  // rj_kernels.hip's code object
+    prewarm_varchar_dev(L, b->as<uint32_t>());                                    // rj_varchar_dev.hip's
+    sync();
 }
 
 hipStream_t Context::upload_stream() {

@@ -34,7 +34,17 @@ struct ColRef {
 enum CarryMode : int32_t {
     CARRY_NONE   = 0,
     CARRY_ROWIDX = 1,  // row index into the child relation (generic path: gather later)
-    CARRY_COLUMN = 2   // the single payload column itself (direct path: no gather)
+    CARRY_COLUMN = 2,  // the single payload column itself (direct path: no gather)
+    CARRY_WIDE   = 3   // several payload columns (and/or a validity word) packed into 2 or 3 carry
+                       // words, see TupleSrc::wide: the values themselves travel, nothing is
+                       // gathered afterwards and nothing refers to a row of this rank
+};
+
+// Layout of a wide carry.  The executor orders the carried columns so that two loaders suffice:
+enum WideLayout : int32_t {
+    WIDE_NONE = 0,  // one column (carry), 32 or 64 bits
+    WIDE_32S  = 1,  // two or three 32-bit columns: carry, carry2 [, carry3]
+    WIDE_64_32 = 2  // a 64-bit column (carry) followed by a 32-bit one (carry2)
 };
 
 struct TupleSrc {
@@ -44,6 +54,9 @@ struct TupleSrc {
     int32_t  carry_mode;
     int32_t  key_f64;    // FP64 key: compared by bit pattern, NaN never matches
     int32_t  prehashed;  // key column already holds hashed keys (sharded stage B)
+    int32_t  wide;       // WideLayout (CARRY_WIDE)
+    int32_t  pad;
+    ColRef   carry2, carry3;  // further columns of a wide carry
 };
 
 // Partitioned tuples are SoA arrays of 32-bit words (or, for one key word + one carry word in
@@ -108,7 +121,24 @@ struct PassParams {
     // 2 bytes per tuple instead of fishing 4-byte keys out of 12-byte tuples; nullptr = none
     uint16_t*       side_out;
     uint32_t        next_shift, next_mask;
+    // Input segments that do not lie one behind the other (what a rank holds after the exchange
+    // of a sharded join: one run per (source rank, local digit), listed digit-major): segment s
+    // is [seg_off[s], seg_end[s]); nullptr = [seg_off[s], seg_off[s + 1])
+    const uint32_t* seg_end;
+    // ... and several input segments may feed ONE output segment (all runs of a local digit):
+    // input segment s belongs to output segment s >> oseg_shift, whose bins / cursors it uses
+    uint32_t        oseg_shift;
+    // Composite digit (stage A of a sharded join: owner rank from the TOP hash bits, first local
+    // digit from the LOW ones, one pass for both): hi_shift != 0 =>
+    //   digit = ((w >> shift) & ((1 << lo_bits) - 1)) | ((w >> hi_shift) << lo_bits)
+    uint32_t        hi_shift, lo_bits;
 };
+
+// digit of hashed key word `w` in this pass (mask = fan-out - 1)
+__host__ __device__ inline uint32_t pass_digit(const PassParams& pp, uint32_t w, uint32_t mask) {
+    if (pp.hi_shift) return (((w >> pp.shift) & ((1u << pp.lo_bits) - 1u)) | ((w >> pp.hi_shift) << pp.lo_bits)) & mask;
+    return (w >> pp.shift) & mask;
+}
 
 // ---- Build/probe -------------------------------------------------------------
 #ifndef RJ_JN_THREADS
@@ -157,7 +187,8 @@ enum StreamMode : int32_t {
     ST_DENSE32 = 1,
     ST_DENSE64 = 2,
     ST_PAGED32 = 3,  // page images, ROWS32 per page, values from +4
-    ST_PAGED64 = 4   // page images, ROWS64 per page, values from +8
+    ST_PAGED64 = 4,  // page images, ROWS64 per page, values from +8
+    ST_DENSE96 = 5   // 12-byte records (a three-word wide carry; two-word ones use ST_DENSE64)
 };
 
 struct OutStream {
@@ -184,6 +215,23 @@ struct JoinParams {
     int32_t         aosR, aosS;   // R.w[0] / S.w[0] is an array of 12-byte {hashed key, carry lo, carry hi}
     int32_t         pad;
     unsigned long long* diag;    // phase cycle counters (RJ_DIAG=1 only), else nullptr
+};
+
+// ---- wide carries: the records a join emits for one side -> its columns (k_split_records)
+struct SplitParams {
+    const uint32_t* rec;         // cw words per output row
+    uint32_t        cw;
+    int32_t         n_cols;
+    int32_t         valid_word;  // word of the record that holds the validity bits, -1 = none
+    int32_t         pad;
+    struct Col {
+        uint8_t* out;            // dense values
+        uint8_t* valid;          // validity bytes, nullptr = the column has no NULLs
+        int32_t  word;           // first word of the column inside the record
+        int32_t  width;          // 4 or 8
+        int32_t  valid_bit;
+        int32_t  pad;
+    } col[3];
 };
 
 // ---- VARCHAR materialisation on the device (rj_varchar_dev.hip) ----------------------------

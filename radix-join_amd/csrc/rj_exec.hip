@@ -17,6 +17,7 @@
 #include <set>
 
 #include "rj_internal.hpp"
+#include "rj_xplan.hpp"
 
 namespace rj {
 
@@ -60,6 +61,24 @@ struct WordSrc {
     bool     packed = false;
 };
 
+// How the FIRST pass of a partition() call differs from the plain "one segment, one bit field"
+// case — both forms belong to the sharded join:
+//   * composite digit (stage A): owner rank from the top hash bits, first local digit from the
+//     low ones, in one pass (PassParams::hi_shift / lo_bits);
+//   * pre-segmented input (stage B): what arrived in the exchange is a set of runs, one per
+//     (source rank, local digit), listed digit-major; `world` of them feed one output segment
+//     (ExchangePlan::seg_begin / seg_end / part_off, rj_xplan.hpp).
+struct PassShape {
+    uint32_t        hi_shift = 0, lo_bits = 0;
+    const uint32_t* seg_begin = nullptr;  // device, [nseg]
+    const uint32_t* seg_end = nullptr;    // device, [nseg]
+    uint32_t        nseg = 0;
+    uint32_t        oseg_shift = 0;       // input segment i feeds output segment i >> oseg_shift
+    const uint32_t* oseg_off = nullptr;   // device, [n_oseg + 1]
+    uint32_t        n_oseg = 0;
+    std::vector<uint32_t> prior_bits;     // digits consumed before this call (for the partition index)
+};
+
 struct JoinSpec {
     bool                  build_left = true;
     uint64_t              left_attr = 0, right_attr = 0;
@@ -67,6 +86,7 @@ struct JoinSpec {
     std::vector<int32_t>  out_type;
     bool                  prehashed = false;
     int                   forced_bits = 0;
+    uint32_t              top_bits_taken = 0;  // high hash bits that are constant in this input
 };
 
 uint32_t ceil_log2(uint64_t v) {
@@ -96,7 +116,7 @@ class Exec {
     }
 
     // rj_join_tuples: same join core over caller-provided dense tuples
-    Result* run_tuples(const rj_tuples* b, const rj_tuples* p, uint32_t /*skip_rank_bits*/) {
+    Result* run_tuples(const rj_tuples* b, const rj_tuples* p, uint32_t skip_rank_bits) {
         std::unique_ptr<Result> res(new rj_result());
         res->ctx = ctx;
         auto mk = [](const rj_tuples* t) {
@@ -121,6 +141,10 @@ class Exec {
         js.out_idx = {0, 1, 3};
         js.out_type = {RJ_INT32, RJ_INT32, RJ_INT32};
         js.prehashed = b->hashed != 0;
+        // the top hash bits stage A consumed are constant on this rank: the radix plan stays
+        // below them (they would only produce empty partitions)
+        if (skip_rank_bits > 16) throw_fmt(RJ_ERR_ARG, "skip_rank_bits > 16");
+        js.top_bits_taken = js.prehashed ? skip_rank_bits : 0u;
         (void)join_core(lb, rp, js, res.get());
         ctx->sync();
         return res.release();
@@ -306,8 +330,10 @@ class Exec {
     // (the sharded join's stage A) copies them out ahead of the scatter.
     Parted partition(const TupleSrc* srcp, const WordSrc* ws, int KW, int CW, uint32_t bits,
                      uint32_t shift0 = 0, bool single_pass = false, const Words* external = nullptr,
-                     const std::function<void(const uint32_t*)>* after_offsets = nullptr) {
+                     const std::function<void(const uint32_t*)>* after_offsets = nullptr,
+                     const PassShape* shape = nullptr) {
         Parted P;
+        const bool preseg = shape && shape->nseg > 0;
         P.NW = KW + CW;
         const TupleSrc none{};
         const TupleSrc& src = srcp ? *srcp : none;
@@ -328,7 +354,7 @@ class Exec {
         // Two passes whose final partitions fit one LDS histogram: both digits are counted in a
         // single read of the source, the scatters reserve their ranges tile by tile, and the
         // second histogram pass (4 B/tuple) disappears.
-        const bool fine = passes == 2 && bits <= (uint32_t)PT_FINEBITS && !external &&
+        const bool fine = passes == 2 && bits <= (uint32_t)PT_FINEBITS && !external && !shape &&
                           ctx->tune.fine != 0;
         // key + one carry word travel as 8-byte pairs in one array (half the streams, twice the
         // bytes per run); RJ_TUNE_PACK: 0 = never, 1 = every plan, 2 = fine-histogram plans only
@@ -345,8 +371,11 @@ class Exec {
         // RJ_TUNE_AOS_MID: 0 never, 1 always, 2 (default) only for fine-histogram plans, which
         // need no digit side array — with it the first pass loses more (+0.8 ms at 1 B rows) than
         // the histogram gains (−0.4 ms): profiles/r02_y_aos_between_passes_ab.log
+        // RJ_TUNE_AOS_MID=3: always, and WITHOUT the side array (the next histogram reads the keys
+        // out of the 12-byte tuples)
         const bool aos_mid = P.aos3 && passes >= 2 &&
-                             (ctx->tune.aos_mid == 1 || (ctx->tune.aos_mid == 2 && fine));
+                             (ctx->tune.aos_mid == 1 || ctx->tune.aos_mid == 3 || (ctx->tune.aos_mid == 2 && fine));
+        const bool mid_side = aos_mid && !fine && ctx->tune.aos_mid != 3;
         BufP  A[MAX_WORDS], B[MAX_WORDS], AOS, MID[2], SIDE[2];
         Words wa{}, wb{}, waos{};
         if (P.aos3) {
@@ -356,7 +385,7 @@ class Exec {
         if (aos_mid) {
             for (uint32_t k = 0; k < std::min<uint32_t>(passes - 1, 2); ++k) {
                 MID[k] = ctx->buf(std::max<uint64_t>(n, 1) * 12);
-                if (!fine) SIDE[k] = ctx->buf(std::max<uint64_t>(n, 1) * 2 + 16);
+                if (mid_side) SIDE[k] = ctx->buf(std::max<uint64_t>(n, 1) * 2 + 16);
             }
         }
         // packed pairs above the fine histogram's limit: a later pass' histogram would read the
@@ -367,11 +396,12 @@ class Exec {
         if (packed_side)
             for (uint32_t k = 0; k < std::min<uint32_t>(passes - 1, 2); ++k)
                 SIDE[k] = ctx->buf(std::max<uint64_t>(n, 1) * 2 + 16);
+        // the last two words of a carry of two or three words are ONE array of 8-byte pairs (at word
+        // pair_word); key + one carry word one array of pairs altogether (packed)
+        const int pair_word = CW >= 2 ? KW + CW - 2 : -1;
         for (int a = 0; a < (P.packed ? 1 : P.NW); ++a) {
-            // a two-word carry is ONE array of 8-byte pairs (at word KW), key + one carry word
-            // one array of pairs altogether (packed)
-            if (CW == 2 && a == KW + 1) continue;
-            const uint64_t wbytes = (P.packed || (CW == 2 && a == KW)) ? 8 : 4;
+            if (pair_word >= 0 && a == pair_word + 1) continue;
+            const uint64_t wbytes = (P.packed || a == pair_word) ? 8 : 4;
             if (external) {
                 wa.w[a] = external->w[a];
                 continue;
@@ -425,7 +455,6 @@ class Exec {
         }
         for (uint32_t p = 0; p < passes; ++p) {
             const uint32_t F = 1u << pbits[p];
-            const uint64_t bins = (uint64_t)nseg * F;
             PassParams     pp{};
             pp.nseg = nseg;
             pp.n = (uint32_t)n;
@@ -433,26 +462,40 @@ class Exec {
             pp.fanout_log2 = pbits[p];
             uint32_t n_groups;
             BufP     grp_start;
-            if (p == 0) {
+            // segments this pass reads / output segments it fills (the same unless the input is a
+            // set of exchanged runs, several of which feed one output segment)
+            const bool      first_preseg = p == 0 && preseg;
+            const uint32_t  nseg_in = first_preseg ? shape->nseg : nseg;
+            const uint32_t  n_oseg = first_preseg ? shape->n_oseg : nseg;
+            const uint64_t  bins = (uint64_t)n_oseg * F;
+            if (p == 0 && shape && shape->hi_shift) {
+                pp.hi_shift = shape->hi_shift;
+                pp.lo_bits = shape->lo_bits;
+            }
+            if (p == 0 && !preseg) {
                 pp.tiles_per_group = tpg_first;
                 uint64_t gt = (uint64_t)pp.tiles_per_group * PT_TILE;
                 n_groups = (uint32_t)((n + gt - 1) / gt);
             } else {
-                    pp.tiles_per_group = tiles_per_group(n / nseg + 1, 16);
+                    pp.tiles_per_group = tiles_per_group(n / nseg_in + 1, 16);
                     uint64_t gt = (uint64_t)pp.tiles_per_group * PT_TILE;
                     if (ctx->tune.tpg2 > 0) {
                         pp.tiles_per_group = (uint32_t)ctx->tune.tpg2;
                         gt = (uint64_t)pp.tiles_per_group * PT_TILE;
                     }
-                    n_groups = (uint32_t)(n / gt + nseg);  // upper bound; exact count lives on device
+                    n_groups = (uint32_t)(n / gt + nseg_in);  // upper bound; exact count lives on device
                     if (ctx->tune.xcd_split && n >= (uint64_t)ctx->tune.xcd_min_rows) {
                         pp.xcd_remap = 1;
                         n_groups += 8;  // 8 * ceil(G / 8) workgroups
                     }
-                    grp_start = ctx->buf(((uint64_t)nseg + 1) * 4);
-                    launch_group_table(L, seg_off->as<uint32_t>(), nseg, (uint32_t)gt,
-                                       grp_start->as<uint32_t>());
-                    pp.seg_off = seg_off->as<uint32_t>();
+                    const uint32_t* in_off = first_preseg ? shape->seg_begin : seg_off->as<uint32_t>();
+                    grp_start = ctx->buf(((uint64_t)nseg_in + 1) * 4);
+                    launch_group_table(L, in_off, nseg_in, (uint32_t)gt, grp_start->as<uint32_t>(),
+                                       first_preseg ? shape->seg_end : nullptr);
+                    pp.nseg = nseg_in;
+                    pp.seg_off = in_off;
+                    pp.seg_end = first_preseg ? shape->seg_end : nullptr;
+                    pp.oseg_shift = first_preseg ? shape->oseg_shift : 0u;
                     pp.grp_start = grp_start->as<uint32_t>();
                 }
                 BufP off, hist, cursor;  // this pass' partition offsets, bin totals, write cursors
@@ -463,7 +506,7 @@ class Exec {
                     pp.xcd_log2 = (p == 0 && fine_xcd) ? 3u : 0u;
                 } else {
                     // sub-ranges per XCD only where a partition gets many runs (big inputs)
-                    pp.xcd_log2 = (ctx->tune.xcd_split && p == 0 && n >= (uint64_t)ctx->tune.xcd_min_rows) ? 3u : 0u;
+                    pp.xcd_log2 = (ctx->tune.xcd_split && p == 0 && !preseg && n >= (uint64_t)ctx->tune.xcd_min_rows) ? 3u : 0u;
                     hist = ctx->buf((bins << pp.xcd_log2) * 4);
                     off = ctx->buf((bins + 1) * 4);
                     cursor = ctx->buf((bins << pp.xcd_log2) * 4);
@@ -472,21 +515,24 @@ class Exec {
                     pp.cursor = cursor->as<uint32_t>();
                     if (p == 0 && !ws)
                         launch_pass_hist_src(L, src, KW, pp, n_groups);
-                    else if ((aos_mid || packed_side) && p > 0)
+                    else if ((mid_side || packed_side) && p > 0)
                         launch_pass_hist_digits(L, SIDE[(p - 1) % 2]->as<uint16_t>(), pp, n_groups);
+                    else if (aos_mid && p > 0)
+                        launch_pass_hist_aos3(L, MID[(p - 1) % 2]->as<uint32_t>(), pp, n_groups);
                     else if (P.packed)
                         launch_pass_hist_packed(L, cur.w[0], pp, n_groups);
                     else
                         launch_pass_hist_dense(L, cur, pp, n_groups);
-                    launch_scan_segments(L, pp.hist, p == 0 ? nullptr : pp.seg_off, nseg, F, pp.xcd_log2,
-                                         off->as<uint32_t>(), pp.cursor);
+                    // (one workgroup per OUTPUT segment; its base = where that segment starts)
+                    launch_scan_segments(L, pp.hist, first_preseg ? shape->oseg_off : (p == 0 ? nullptr : pp.seg_off),
+                                         n_oseg, F, pp.xcd_log2, off->as<uint32_t>(), pp.cursor);
                 }
                 if (p == 0 && after_offsets) (*after_offsets)(off->as<uint32_t>());
                 if (aos_mid) {
                     const bool last = p + 1 == passes;
                     Words      o{};
                     o.w[0] = last ? waos.w[0] : MID[p % 2]->as<uint32_t>();
-                    if (!last && !fine) {
+                    if (!last && mid_side) {
                         pp.side_out = SIDE[p % 2]->as<uint16_t>();
                         pp.next_shift = shift + pbits[p];
                         pp.next_mask = (1u << pbits[p + 1]) - 1u;
@@ -511,7 +557,7 @@ class Exec {
                 } else if (p == 0 && !ws) {
                     launch_pass_scatter_src(L, src, KW, CW, pp, n_groups, nxt, P.aos3 && p + 1 == passes);
                 } else {
-                    launch_pass_scatter_dense(L, cur, P.NW, CW == 2 ? KW : -1, pp, n_groups, nxt,
+                    launch_pass_scatter_dense(L, cur, P.NW, pair_word, pp, n_groups, nxt,
                                               P.aos3 && p + 1 == passes);
                 }
                 seg_off = off;
@@ -532,6 +578,7 @@ class Exec {
             P.off = seg_off;
             P.NP = nseg;
             P.pbits = pbits;
+            if (shape && !shape->prior_bits.empty()) P.pbits.insert(P.pbits.begin(), shape->prior_bits.begin(), shape->prior_bits.end());
             P.n_tuples = n;
             return P;
         }
@@ -546,6 +593,16 @@ class Exec {
             int           CW = 0;
             BufP          stream;     // emitted carry stream
             int           stream_mode = ST_NONE;
+            // CARRY_WIDE: the carried columns in record order (a 64-bit one first), then — if any of
+            // them has NULLs — one word of validity bits (bit i = wide_cols[i] is non-NULL)
+            std::vector<int> wide_cols;
+            int              wide = WIDE_NONE;
+            int              valid_word = -1;
+            BufP             vword;  // the packed validity word per row of the child
+            struct WideOut {
+                BufP values, valid;
+            };
+            std::map<int, WideOut> wide_out;  // per carried column: what k_split_records produced
         };
 
         static uint64_t pages_for(uint64_t rows, int width) {
@@ -651,12 +708,52 @@ class Exec {
                     s->carry_mode = CARRY_COLUMN;
                     s->carry_col = *s->need.begin();
                     s->CW = s->rel->cols[s->carry_col].width / 4;
+                } else if (plan_wide_carry(*s, st.KW)) {
+                    s->carry_mode = CARRY_WIDE;
                 } else {
                     s->carry_mode = CARRY_ROWIDX;
                     s->CW = 1;
                 }
             }
             st.cap_hint = std::max(left.n, right.n);
+        }
+
+        // Can the columns a side must deliver travel WITH the key (reference src/execute.cpp:236-242
+        // copies any column list per output row; here up to MAX_WORDS - KW carry words do the same
+        // without a row index to gather through afterwards)?  Layouts: two or three 32-bit words, or
+        // a 64-bit column followed by one 32-bit word; a validity word counts as a 32-bit word.
+        bool plan_wide_carry(Side& s, int KW) {
+            if (!ctx->tune.wide_carry || s.need.empty()) return false;
+            int  words = 0, n64 = 0;
+            bool any_null = false;
+            for (int c : s.need) {
+                const DCol& col = s.rel->cols[c];
+                if (col.width != 4 && col.width != 8) return false;
+                words += col.width / 4;
+                n64 += col.width == 8;
+                any_null = any_null || col.valid != nullptr;
+            }
+            if (any_null) ++words;
+            if (words < 2 || words > MAX_WORDS - KW || n64 > 1 || (n64 == 1 && words != 3)) return false;
+            s.wide_cols.clear();
+            for (int c : s.need)
+                if (s.rel->cols[c].width == 8) s.wide_cols.push_back(c);
+            for (int c : s.need)
+                if (s.rel->cols[c].width == 4) s.wide_cols.push_back(c);
+            s.wide = n64 ? WIDE_64_32 : WIDE_32S;
+            s.valid_word = any_null ? words - 1 : -1;
+            s.CW = words;
+            return true;
+        }
+
+        // validity bits of a wide carry's columns, one word per row (k_pack_validity); call once
+        // per join before the side's tuples are formed
+        void prepare_wide(Side& s) {
+            if (s.carry_mode != CARRY_WIDE || s.valid_word < 0 || s.rel->n == 0) return;
+            const uint8_t* v[3] = {nullptr, nullptr, nullptr};
+            for (size_t i = 0; i < s.wide_cols.size() && i < 3; ++i) v[i] = s.rel->cols[s.wide_cols[i]].valid;
+            s.vword = ctx->buf(s.rel->n * 4);
+            launch_pack_validity(L, v[0], v[1], v[2], (uint32_t)s.rel->n, s.vword->as<uint32_t>());
         }
 
         // radix bit plan from the build cardinality; `top_bits_taken` high hash bits are constant
@@ -685,6 +782,17 @@ class Exec {
                 // a base table's row-id column (VARCHAR stand-in) IS the row index
                 if (src.carry.kind == COL_IOTA) src.carry_mode = CARRY_ROWIDX;
             }
+            if (s.carry_mode == CARRY_WIDE) {
+                ColRef refs[3] = {};
+                size_t k = 0;
+                for (int c : s.wide_cols) refs[k++] = s.rel->cols[c].ref();
+                if (s.valid_word >= 0)
+                    refs[k++] = ColRef{s.vword ? s.vword->as<uint8_t>() : nullptr, nullptr, COL_DENSE, 4};
+                src.wide = s.wide;
+                src.carry = refs[0];
+                src.carry2 = refs[1];
+                src.carry3 = refs[2];
+            }
             src.key_f64 = st.f64 ? 1 : 0;
             src.prehashed = js.prehashed ? 1 : 0;
             return src;
@@ -698,9 +806,11 @@ class Exec {
             join_prepare(left, right, js, root_res != nullptr, st);
             if (st.type_mismatch) return empty_rel(js, root_res);
             if (st.vkey) hash_varchar_keys(st);
+            prepare_wide(st.ls);
+            prepare_wide(st.rs);
             Side&          bs = st.bs();
             Side&          ps = st.ps();
-            const uint32_t bits = join_bits(js, bs.rel->n);
+            const uint32_t bits = join_bits(js, bs.rel->n, js.top_bits_taken);
             if (ctx->tune.diag >= 2)
                 fprintf(stderr, "[rj diag] join build=%llu probe=%llu bits=%u cw=%d/%d\n",
                         (unsigned long long)bs.rel->n, (unsigned long long)ps.rel->n, bits, bs.CW, ps.CW);
@@ -750,6 +860,7 @@ class Exec {
                 case ST_DENSE64: return rows * 8;
                 case ST_PAGED32: return pages_for(rows, 4) * PAGE_BYTES;
                 case ST_PAGED64: return pages_for(rows, 8) * PAGE_BYTES;
+                case ST_DENSE96: return rows * 12;
                 default: return 0;
                 }
             };
@@ -759,6 +870,8 @@ class Exec {
                     s->stream_mode = ST_NONE;
                 else if (s->carry_mode == CARRY_ROWIDX)
                     s->stream_mode = ST_DENSE32;
+                else if (s->carry_mode == CARRY_WIDE)
+                    s->stream_mode = s->CW == 2 ? ST_DENSE64 : ST_DENSE96;  // records, split below
                 else {
                     const DCol& c = s->rel->cols[s->carry_col];
                     s->stream_mode = stream_mode(c.width, c.type != RJ_VARCHAR);
@@ -867,6 +980,31 @@ class Exec {
 
         if (st.vkey && nrows) nrows = verify_varchar_pairs(st, nrows);
 
+        // wide carries: the emitted records -> one dense array (+ validity bytes) per column
+        for (Side* s : {&ls, &rs}) {
+            if (s->carry_mode != CARRY_WIDE) continue;
+            SplitParams sp{};
+            sp.rec = s->stream->as<uint32_t>();
+            sp.cw = (uint32_t)s->CW;
+            sp.valid_word = s->valid_word;
+            int word = 0;
+            for (size_t i = 0; i < s->wide_cols.size(); ++i) {
+                const DCol&   col = s->rel->cols[s->wide_cols[i]];
+                Side::WideOut wo;
+                wo.values = ctx->buf(std::max<uint64_t>(nrows, 1) * col.width);
+                if (col.valid) wo.valid = ctx->buf(std::max<uint64_t>(nrows, 1));
+                sp.col[i].out = wo.values->as<uint8_t>();
+                sp.col[i].valid = wo.valid ? wo.valid->as<uint8_t>() : nullptr;
+                sp.col[i].word = word;
+                sp.col[i].width = col.width;
+                sp.col[i].valid_bit = (int32_t)i;
+                word += col.width / 4;
+                s->wide_out[s->wide_cols[i]] = wo;
+            }
+            sp.n_cols = (int32_t)s->wide_cols.size();
+            launch_split_records(L, sp, nrows);
+        }
+
         // ------------------------------------------------ assemble the outputs
         Rel out;
         out.n = nrows;
@@ -891,6 +1029,11 @@ class Exec {
             } else if (s.carry_mode == CARRY_COLUMN) {
                 buf = s.stream;
                 buf_mode = s.stream_mode;
+            } else if (s.carry_mode == CARRY_WIDE) {
+                const Side::WideOut& wo = s.wide_out.at(c);
+                buf = wo.values;
+                valid = wo.valid;
+                buf_mode = src.width == 4 ? ST_DENSE32 : ST_DENSE64;
             } else {
                 // generic path: gather the child column through the row-index stream
                 const uint32_t* idx = s.stream->as<uint32_t>();
@@ -1164,10 +1307,17 @@ class ShardedExec {
             sync_all();
         } catch (...) {
             // kernels and copies still queued may reference buffers about to be released
+            // (compute streams never wait on an unfinished exchange — see stage B — so they drain;
+            // the exchange streams are waited for with the transport's bound, unless it gave up)
             for (int l = 0; l < nl_; ++l) {
                 (void)hipSetDevice(g_->lane(l)->device);
                 (void)hipStreamSynchronize(g_->lane(l)->stream);
-                if (comm_) (void)hipStreamSynchronize(comm_->xfer_stream(l));
+                if (comm_ && !comm_->failed()) {
+                    try {
+                        comm_->wait_stream(l, "the exchange streams (after an error)");
+                    } catch (...) {
+                    }
+                }
             }
             (void)hipSetDevice(g_->device);
             throw;
@@ -1232,8 +1382,51 @@ class ShardedExec {
     static uint32_t array_width(const Parted& P, int KW, int CW, int a) {
         if (P.packed) return a == 0 ? 8u : 0u;
         if (a >= P.NW) return 0;
-        if (CW == 2 && a == KW + 1) return 0;       // second half of the pair array
-        return (CW == 2 && a == KW) ? 8u : 4u;
+        const int pw = CW >= 2 ? KW + CW - 2 : -1;  // the last two carry words are one pair array
+        if (pw >= 0 && a == pw + 1) return 0;
+        return a == pw ? 8u : 4u;
+    }
+
+    // A local failure on one rank must not leave its peers blocked in a collective: every rank
+    // reports a status word with the counts it all-gathers anyway, and ALL ranks give up together,
+    // before any data moves.  The failing rank rethrows its own error, the others name it.
+    struct LocalErr {
+        int         code = 0;
+        std::string msg;
+    };
+    template <class F>
+    static void guarded(LocalErr& e, F&& f) {
+        if (e.code) return;  // this rank failed earlier: it only keeps the collectives company
+        try {
+            f();
+        } catch (const rj::Error& x) {
+            e.code = x.code ? x.code : RJ_ERR_DEVICE;
+            e.msg = x.what();
+        } catch (const std::bad_alloc&) {
+            e.code = RJ_ERR_NOMEM;
+            e.msg = "host allocation failed";
+        } catch (const std::exception& x) {
+            e.code = RJ_ERR_DEVICE;
+            e.msg = x.what();
+        }
+    }
+    void agree(const std::vector<std::vector<uint64_t>>& all, size_t status_at, const std::vector<LocalErr>& lerr,
+               const char* doing) {
+        int bad = -1;
+        for (int r = 0; r < world_ && bad < 0; ++r)
+            if (all[r][status_at] != 0) bad = r;
+        if (bad < 0) return;
+        for (int l = 0; l < nl_; ++l)
+            if (lerr[l].code) throw rj::Error(lerr[l].code, lerr[l].msg);
+        throw_fmt(RJ_ERR_DEVICE, "sharded join: rank %d failed (status %llu) while %s; every rank gives up before the exchange",
+                  bad, (unsigned long long)all[bad][status_at], doing);
+    }
+    void inject_failure(int at, int lane) {
+        if (g_->tune.debug_shard_fail == at && g_->tune.debug_shard_fail_rank == rank_base_ + lane)
+            throw_fmt(RJ_ERR_NOMEM, "injected failure %d on rank %d (RJ_DEBUG_SHARD_FAIL)", at, rank_base_ + lane);
+    }
+    void wait_xfer(int l, const char* what) {
+        if (comm_) comm_->wait_stream(l, what);
     }
 
     std::vector<Rel> join(std::vector<Rel>& left, std::vector<Rel>& right, const JoinSpec& js,
@@ -1244,29 +1437,34 @@ class ShardedExec {
         auto       lap = [&](const char* what) {
             if (!diag) return;
             sync_all();
-            if (comm_)
-                for (int l = 0; l < nl_; ++l) {
-                    use(l);
-                    RJ_HIP(hipStreamSynchronize(comm_->xfer_stream(l)));
-                }
+            for (int l = 0; l < nl_; ++l) wait_xfer(l, what);
             auto now = std::chrono::steady_clock::now();
             fprintf(stderr, "[rj sharded] rank %d: %-28s %8.2f ms\n", rank_base_, what,
                     std::chrono::duration<double, std::milli>(now - t_start).count());
             t_start = now;
         };
         // ---- what every rank decides locally, then agrees on globally
+        std::vector<LocalErr>              lerr((size_t)nl_);
         std::vector<std::vector<uint64_t>> mine((size_t)nl_), all;
         for (int l = 0; l < nl_; ++l) {
-            use(l);
-            ex_[l]->join_prepare(left[l], right[l], js, root_res != nullptr, st[l]);
             bool ok = true;
-            for (Exec::Side* s : {&st[l].ls, &st[l].rs}) {
-                if (s->carry_mode == CARRY_ROWIDX) ok = false;  // a row index means nothing on another rank
-                if (s->carry_mode == CARRY_COLUMN && s->rel->cols[s->carry_col].kind == COL_IOTA) ok = false;
-            }
-            mine[l] = {left[l].n, right[l].n, ok ? 1ull : 0ull};
+            guarded(lerr[l], [&] {
+                use(l);
+                inject_failure(1, l);
+                ex_[l]->join_prepare(left[l], right[l], js, root_res != nullptr, st[l]);
+                for (Exec::Side* s : {&st[l].ls, &st[l].rs}) {
+                    if (s->carry_mode == CARRY_ROWIDX) ok = false;  // a row index means nothing on another rank
+                    if (s->carry_mode == CARRY_COLUMN && s->rel->cols[s->carry_col].kind == COL_IOTA) ok = false;
+                    if (s->carry_mode == CARRY_WIDE)
+                        for (int c : s->wide_cols)
+                            if (s->rel->cols[c].kind == COL_IOTA || s->rel->cols[c].type == RJ_VARCHAR) ok = false;
+                    ex_[l]->prepare_wide(*s);
+                }
+            });
+            mine[l] = {left[l].n, right[l].n, ok ? 1ull : 0ull, (uint64_t)lerr[l].code};
         }
-        gather(mine, 3, all);
+        gather(mine, 4, all);
+        agree(all, 3, lerr, "preparing the join");
         uint64_t tot_left = 0, tot_right = 0;
         bool     ok = true;
         for (int r = 0; r < world_; ++r) {
@@ -1287,117 +1485,160 @@ class ShardedExec {
         if (tot_left == 0 || tot_right == 0 || st[0].type_mismatch) return all_empty();
         if (!ok)
             throw_fmt(RJ_ERR_UNSUPPORTED,
-                      "sharded join: a side needs more than one non-key column, a nullable or a VARCHAR "
-                      "column (its row index would travel, and means nothing on another rank)");
+                      "sharded join: a side needs more payload than travels with the key (more than %d carry "
+                      "words incl. a validity word, or a VARCHAR column): its row index would travel, and "
+                      "means nothing on another rank",
+                      MAX_WORDS - st[0].KW);
         const int KW = st[0].KW;
+
+        // ---- the radix plan, from totals every rank knows: L local bits per rank, of which the
+        // first digit (s bits) rides on stage A's pass together with the owner digit (rb_ bits) —
+        // stage A fans out world * 2^s ways, and stage B starts at the second local digit
+        const uint64_t tot_build = js.build_left ? tot_left : tot_right;
+        const uint32_t Lbits = ex_[0]->join_bits(js, std::max<uint64_t>((tot_build + world_ - 1) / world_, 1), rb_);
+        const uint32_t sbits = (g_->tune.fold_owner && Lbits >= 2 && rb_ < (uint32_t)PT_MAXBITS)
+                                   ? std::min<uint32_t>(Lbits - 1, (uint32_t)PT_MAXBITS - rb_)
+                                   : 0u;
+        const uint32_t S = 1u << sbits, FA = (uint32_t)world_ * S;
 
         // ---- stage A on every local rank, both sides
         struct SideX {
-            Parted                A;       // partitioned by owner rank
-            std::vector<uint32_t> off;     // [world + 1] host copy of A.off
+            Parted                A;       // partitioned by (owner rank, first local digit)
             BufP                  recv[MAX_WORDS];
             WordSrc               ws;      // what arrived
             Ev                    ready, done, counted;
+            ExchangePlan          plan;
+            BufP                  segs;    // device copy of plan.seg_begin | seg_end | part_off
             Parted                P;       // stage B partitions
         };
         std::vector<SideX> bx((size_t)nl_), px((size_t)nl_);
-        const uint32_t     shiftA = rb_ ? 32 - rb_ : 31;
-        if ((size_t)world_ + 1 > Context::SMALL_PINNED / 8)
-            throw_fmt(RJ_ERR_UNSUPPORTED, "sharded join: more than %zu ranks", Context::SMALL_PINNED / 8 - 1);
+        if (((size_t)FA + 1) * 4 > Context::SMALL_PINNED / 2)
+            throw_fmt(RJ_ERR_UNSUPPORTED, "sharded join: more than %zu stage-A partitions", Context::SMALL_PINNED / 8 - 1);
         for (int l = 0; l < nl_; ++l) {
-            use(l);
-            Exec&    E = *ex_[l];
-            Context* c = g_->lane(l);
-            for (int side = 0; side < 2; ++side) {
-                Exec::Side& s = side == 0 ? st[l].bs() : st[l].ps();
-                SideX&      X = side == 0 ? bx[l] : px[l];
-                TupleSrc    src = E.make_src(st[l], s, js);
-                X.ready.make();
-                X.done.make();
-                X.counted.make();
-                // the per-owner counts leave for the host BEFORE the scatter is enqueued: the
-                // host sizes and starts the exchange of the build side while the probe side's
-                // scatter is still running
-                uint32_t* host_off = static_cast<uint32_t*>(c->small_pinned()) + (size_t)side * (Context::SMALL_PINNED / 8);
-                const std::function<void(const uint32_t*)> counts_out = [&](const uint32_t* off) {
-                    RJ_HIP(hipMemcpyAsync(host_off, off, ((size_t)world_ + 1) * 4, hipMemcpyDeviceToHost, c->stream));
-                    RJ_HIP(hipEventRecord(X.counted.e, c->stream));
-                };
-                X.A = E.partition(&src, nullptr, KW, s.CW, rb_, shiftA, /*single pass*/ true, nullptr, &counts_out);
-                RJ_HIP(hipEventRecord(X.ready.e, c->stream));
-            }
+            guarded(lerr[l], [&] {
+                use(l);
+                inject_failure(2, l);
+                Exec&    E = *ex_[l];
+                Context* c = g_->lane(l);
+                for (int side = 0; side < 2; ++side) {
+                    Exec::Side& s = side == 0 ? st[l].bs() : st[l].ps();
+                    SideX&      X = side == 0 ? bx[l] : px[l];
+                    TupleSrc    src = E.make_src(st[l], s, js);
+                    X.ready.make();
+                    X.done.make();
+                    X.counted.make();
+                    // the per-partition offsets leave for the host BEFORE the scatter is enqueued: the
+                    // host sizes and starts the exchange of the build side while the probe side's
+                    // scatter is still running
+                    uint32_t* host_off = static_cast<uint32_t*>(c->small_pinned()) + (size_t)side * (Context::SMALL_PINNED / 8);
+                    const std::function<void(const uint32_t*)> counts_out = [&](const uint32_t* off) {
+                        RJ_HIP(hipMemcpyAsync(host_off, off, ((size_t)FA + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+                        RJ_HIP(hipEventRecord(X.counted.e, c->stream));
+                    };
+                    PassShape shape;
+                    if (rb_ && sbits) {
+                        shape.hi_shift = 32 - rb_;
+                        shape.lo_bits = sbits;
+                    }
+                    // one field when only one of the two digits exists: the owner's (top bits) or the local one's (low bits)
+                    const uint32_t shiftA = sbits ? 0u : (rb_ ? 32 - rb_ : 31);
+                    X.A = E.partition(&src, nullptr, KW, s.CW, rb_ + sbits, shiftA, /*single pass*/ true, nullptr, &counts_out,
+                                      shape.hi_shift ? &shape : nullptr);
+                    RJ_HIP(hipEventRecord(X.ready.e, c->stream));
+                }
+            });
         }
+        // ---- who holds how much for whom: cnt[src rank][side][dst rank][digit], + a status word
+        const size_t per_side = (size_t)world_ * S;
         for (int l = 0; l < nl_; ++l) {
-            use(l);
-            Context* c = g_->lane(l);
-            for (int side = 0; side < 2; ++side) {
-                SideX& X = side == 0 ? bx[l] : px[l];
-                RJ_HIP(hipEventSynchronize(X.counted.e));
-                const uint32_t* host_off = static_cast<const uint32_t*>(c->small_pinned()) + (size_t)side * (Context::SMALL_PINNED / 8);
-                X.off.assign(host_off, host_off + world_ + 1);
-            }
+            mine[l].assign(2 * per_side + 1, 0);
+            guarded(lerr[l], [&] {
+                use(l);
+                Context* c = g_->lane(l);
+                for (int side = 0; side < 2; ++side) {
+                    SideX& X = side == 0 ? bx[l] : px[l];
+                    RJ_HIP(hipEventSynchronize(X.counted.e));  // (this rank's own stream: finite)
+                    const uint32_t* off = static_cast<const uint32_t*>(c->small_pinned()) + (size_t)side * (Context::SMALL_PINNED / 8);
+                    for (size_t q = 0; q < per_side; ++q) mine[l][side * per_side + q] = off[q + 1] - off[q];
+                }
+            });
+            if (lerr[l].code) mine[l].assign(2 * per_side + 1, 0);
+            mine[l][2 * per_side] = (uint64_t)lerr[l].code;
         }
         lap("stage A (histograms on the host; scatters may still run)");
-
-        // ---- who sends how much to whom: cnt[src rank][side * world + dst rank]
-        for (int l = 0; l < nl_; ++l) {
-            mine[l].assign((size_t)2 * world_, 0);
-            for (int d = 0; d < world_; ++d) {
-                mine[l][d] = bx[l].off[d + 1] - bx[l].off[d];
-                mine[l][(size_t)world_ + d] = px[l].off[d + 1] - px[l].off[d];
-            }
-        }
-        gather(mine, (size_t)2 * world_, all);
+        gather(mine, 2 * per_side + 1, all);
+        agree(all, 2 * per_side, lerr, "partitioning its shard (stage A)");
         lap("count all-gather");
+
+        // ---- the exchange layout (host arithmetic, rj_xplan.cpp).  Whether a rank would receive
+        // more than 2^32 tuples is decided for EVERY rank of the world from the same tensor, so
+        // all ranks throw the same error here — none of them enters the collective alone.
+        std::vector<uint64_t> cnt[2];
+        for (int side = 0; side < 2; ++side) {
+            cnt[side].resize((size_t)world_ * per_side);
+            for (int r = 0; r < world_; ++r)
+                std::copy(all[r].begin() + side * per_side, all[r].begin() + (side + 1) * per_side,
+                          cnt[side].begin() + (size_t)r * per_side);
+            const int over = exchange_first_overflow((uint32_t)world_, S, cnt[side].data());
+            if (over >= 0)
+                throw_fmt(RJ_ERR_UNSUPPORTED, "sharded join: rank %d would receive more than 2^32 tuples of the %s side", over,
+                          side == 0 ? "build" : "probe");
+        }
+        // receive buffers (a local allocation may fail: agreed on with one more status word)
+        for (int l = 0; l < nl_; ++l) {
+            guarded(lerr[l], [&] {
+                use(l);
+                inject_failure(3, l);
+                Context* c = g_->lane(l);
+                for (int side = 0; side < 2; ++side) {
+                    SideX&    X = side == 0 ? bx[l] : px[l];
+                    const int CW = side == 0 ? st[l].bs().CW : st[l].ps().CW;
+                    exchange_plan((uint32_t)world_, S, (uint32_t)(rank_base_ + l), cnt[side].data(), X.plan);
+                    X.ws.n = X.plan.n_recv;
+                    X.ws.packed = X.A.packed;
+                    for (int a = 0; a < MAX_WORDS; ++a) {
+                        const uint32_t wbytes = array_width(X.A, KW, CW, a);
+                        if (!wbytes) continue;
+                        X.recv[a] = c->buf(std::max<uint64_t>(X.plan.n_recv, 1) * wbytes);
+                        X.ws.w.w[a] = X.recv[a]->as<uint32_t>();
+                    }
+                    if (S > 1) {  // the runs that arrive, as input segments of stage B's first pass
+                        const size_t ns = X.plan.seg_begin.size();
+                        X.segs = c->buf((2 * ns + S + 1) * 4);
+                        uint32_t* d = X.segs->as<uint32_t>();
+                        RJ_HIP(hipMemcpyAsync(d, X.plan.seg_begin.data(), ns * 4, hipMemcpyHostToDevice, c->stream));
+                        RJ_HIP(hipMemcpyAsync(d + ns, X.plan.seg_end.data(), ns * 4, hipMemcpyHostToDevice, c->stream));
+                        RJ_HIP(hipMemcpyAsync(d + 2 * ns, X.plan.part_off.data(), ((size_t)S + 1) * 4, hipMemcpyHostToDevice,
+                                              c->stream));
+                    }
+                }
+            });
+            mine[l] = {(uint64_t)lerr[l].code};
+        }
+        gather(mine, 1, all);
+        agree(all, 0, lerr, "allocating its receive buffers");
 
         // ---- the exchange: build side first, probe side queued behind it on the exchange streams
         for (int side = 0; side < 2; ++side) {
             std::vector<SideX>& XS = side == 0 ? bx : px;
             // arrays of the partition layout (the same on every rank: KW, CW and the packing rule agree)
             const int CW = side == 0 ? st[0].bs().CW : st[0].ps().CW;
-            int       n_arrays = 0;
-            for (int a = 0; a < MAX_WORDS; ++a)
-                if (array_width(XS[0].A, KW, CW, a)) n_arrays = a + 1;
-            std::vector<uint64_t> n_recv((size_t)nl_, 0);
-            for (int l = 0; l < nl_; ++l) {
-                use(l);
-                const int me = rank_base_ + l;
-                for (int s = 0; s < world_; ++s) n_recv[l] += all[s][(size_t)side * world_ + me];
-                if (n_recv[l] > 0xfffffff0ull) throw_fmt(RJ_ERR_UNSUPPORTED, "more than 2^32 tuples on one rank");
-                SideX& X = XS[l];
-                X.ws.n = n_recv[l];
-                X.ws.packed = X.A.packed;
-                for (int a = 0; a < n_arrays; ++a) {
-                    const uint32_t wbytes = array_width(X.A, KW, CW, a);
-                    if (!wbytes) continue;
-                    X.recv[a] = g_->lane(l)->buf(std::max<uint64_t>(n_recv[l], 1) * wbytes);
-                    X.ws.w.w[a] = X.recv[a]->as<uint32_t>();
-                }
-            }
             // one all-to-all per relation: every array of the layout travels in the same group
             std::vector<std::vector<XferSpec>> specs((size_t)nl_);
             std::vector<hipEvent_t>            ready, done;
             for (int l = 0; l < nl_; ++l) {
-                const int me = rank_base_ + l;
-                SideX&    X = XS[l];
-                for (int a = 0; a < n_arrays; ++a) {
+                SideX& X = XS[l];
+                for (int a = 0; a < MAX_WORDS; ++a) {
                     const uint32_t wbytes = array_width(X.A, KW, CW, a);
                     if (!wbytes) continue;
                     XferSpec sp;
                     sp.send = reinterpret_cast<const uint8_t*>(X.A.w.w[a]);
                     sp.recv = reinterpret_cast<uint8_t*>(X.ws.w.w[a]);
-                    sp.send_off.assign((size_t)world_, 0);
-                    sp.send_cnt.assign((size_t)world_, 0);
-                    sp.recv_off.assign((size_t)world_, 0);
-                    sp.recv_cnt.assign((size_t)world_, 0);
-                    uint64_t roff = 0;
                     for (int r = 0; r < world_; ++r) {
-                        sp.send_off[r] = (uint64_t)X.off[r] * wbytes;
-                        sp.send_cnt[r] = (uint64_t)(X.off[r + 1] - X.off[r]) * wbytes;
-                        const uint64_t c = all[r][(size_t)side * world_ + me];
-                        sp.recv_off[r] = roff * wbytes;
-                        sp.recv_cnt[r] = c * wbytes;
-                        roff += c;
+                        sp.send_off.push_back(X.plan.send_off[r] * wbytes);
+                        sp.send_cnt.push_back(X.plan.send_cnt[r] * wbytes);
+                        sp.recv_off.push_back(X.plan.recv_off[r] * wbytes);
+                        sp.recv_cnt.push_back(X.plan.recv_cnt[r] * wbytes);
                     }
                     specs[l].push_back(std::move(sp));
                 }
@@ -1415,39 +1656,42 @@ class ShardedExec {
         }
 
         lap("exchange (both sides)");
-        // ---- stage B: each rank joins what it owns
+        // ---- stage B: each rank joins what it owns.  The host waits for an exchange with a
+        // bound (Comm::wait_event) BEFORE it makes the compute stream depend on it, so no stream
+        // and no host thread of this rank ever sits behind a peer that is gone.
         std::vector<Rel> out((size_t)nl_);
-        std::vector<uint32_t> bits((size_t)nl_);
-        for (int l = 0; l < nl_; ++l) {
-            use(l);
-            Exec&    E = *ex_[l];
-            Context* c = g_->lane(l);
-            bits[l] = E.join_bits(js, std::max<uint64_t>(bx[l].ws.n, 1), rb_);
-            RJ_HIP(hipStreamWaitEvent(c->stream, bx[l].done.e, 0));
-            bx[l].P = E.partition(nullptr, &bx[l].ws, KW, st[l].bs().CW, bits[l]);
-        }
-        for (int l = 0; l < nl_; ++l) {
-            use(l);
-            Exec&    E = *ex_[l];
-            Context* c = g_->lane(l);
-            RJ_HIP(hipStreamWaitEvent(c->stream, px[l].done.e, 0));
-            px[l].P = E.partition(nullptr, &px[l].ws, KW, st[l].ps().CW, bits[l]);
-        }
+        auto stage_b = [&](int l, SideX& X, int CW) {
+            Exec& E = *ex_[l];
+            if (S == 1) return E.partition(nullptr, &X.ws, KW, CW, Lbits);
+            const size_t ns = X.plan.seg_begin.size();
+            PassShape    shape;
+            shape.seg_begin = X.segs->as<uint32_t>();
+            shape.seg_end = shape.seg_begin + ns;
+            shape.oseg_off = shape.seg_begin + 2 * ns;
+            shape.nseg = (uint32_t)ns;
+            shape.n_oseg = S;
+            shape.oseg_shift = rb_;  // `world` runs per digit
+            shape.prior_bits = {sbits};
+            return E.partition(nullptr, &X.ws, KW, CW, Lbits - sbits, sbits, false, nullptr, nullptr, &shape);
+        };
+        for (int side = 0; side < 2; ++side)
+            for (int l = 0; l < nl_; ++l) {
+                SideX& X = side == 0 ? bx[l] : px[l];
+                if (comm_) comm_->wait_event(l, X.done.e, side == 0 ? "the exchange of the build side" : "the exchange of the probe side");
+                use(l);
+                RJ_HIP(hipStreamWaitEvent(g_->lane(l)->stream, X.done.e, 0));
+                X.P = stage_b(l, X, side == 0 ? st[l].bs().CW : st[l].ps().CW);
+            }
         for (int l = 0; l < nl_; ++l) {
             use(l);
             st[l].cap_hint = std::max(bx[l].ws.n, px[l].ws.n);
-            out[l] = ex_[l]->join_finish(st[l], js, &bx[l].P, &px[l].P, bits[l],
-                                         root_res ? (*root_res)[l] : nullptr);
+            out[l] = ex_[l]->join_finish(st[l], js, &bx[l].P, &px[l].P, Lbits, root_res ? (*root_res)[l] : nullptr);
         }
         lap("stage B (passes + join)");
         // stage A's arrays were read by the exchange streams (and by peers): they may go back
-        // to the block caches only now that every rank has waited for its incoming copies
+        // to the block caches only now that every rank's outgoing copies have left
         sync_all();
-        if (comm_)
-            for (int l = 0; l < nl_; ++l) {
-                use(l);
-                RJ_HIP(hipStreamSynchronize(comm_->xfer_stream(l)));
-            }
+        for (int l = 0; l < nl_; ++l) wait_xfer(l, "the exchange streams");
         return out;
     }
 
@@ -1476,19 +1720,41 @@ bool node_shardable(const rj_plan* plan, uint64_t idx, int depth, std::string* w
     if (!node_shardable(plan, n.left, depth + 1, why) || !node_shardable(plan, n.right, depth + 1, why))
         return false;
     if (n.left >= plan->n_nodes || n.right >= plan->n_nodes) return false;
-    const uint64_t lw = plan->nodes[n.left].n_out;
+    const uint64_t lw = plan->nodes[n.left].n_out, rw = plan->nodes[n.right].n_out;
+    if (n.left_attr >= lw || n.right_attr >= rw) return false;
+    // what must travel with the key on each side: up to MAX_WORDS - KW carry words (a nullable
+    // column needs one word more for its validity bits — known only at run time, where the ranks
+    // then agree to refuse the join together)
+    const rj_node& build = n.build_left ? plan->nodes[n.left] : plan->nodes[n.right];
+    const int32_t  key_type = build.out_type[n.build_left ? n.left_attr : n.right_attr];
+    const int      KW = key_type == RJ_INT32 ? 1 : 2;
     std::set<uint64_t> need_l, need_r;
     for (uint64_t k = 0; k < n.n_out; ++k) {
         const uint64_t c = n.out_idx[k];
+        if (c >= lw + rw) return false;
         if (c < lw) {
             if (c != n.left_attr) need_l.insert(c);
         } else if (c - lw != n.right_attr) {
             need_r.insert(c - lw);
         }
     }
-    if (need_l.size() > 1 || need_r.size() > 1) {
-        if (why) *why = "a join side needs more than one non-key column";
-        return false;
+    auto words = [&](const rj_node& child, const std::set<uint64_t>& need, int& n64) {
+        int w = 0;
+        n64 = 0;
+        for (uint64_t c : need) {
+            const bool wide = child.out_type[c] == RJ_INT64 || child.out_type[c] == RJ_FP64;
+            w += wide ? 2 : 1;
+            n64 += wide;
+        }
+        return w;
+    };
+    for (int side = 0; side < 2; ++side) {
+        int       n64 = 0;
+        const int w = words(side == 0 ? plan->nodes[n.left] : plan->nodes[n.right], side == 0 ? need_l : need_r, n64);
+        if (w > MAX_WORDS - KW || n64 > 1 || (n64 == 1 && w == 4)) {
+            if (why) *why = "a join side needs more payload than travels with the key (more than 3 carry words, or two 64-bit columns)";
+            return false;
+        }
     }
     return true;
 }

@@ -187,6 +187,16 @@ struct Tuning {
     int vkey_hash_bits = 0;  // RJ_DEBUG_VKEY_HASH_BITS: keep only this many bits of a VARCHAR key's hash
                              // (tests: forces collisions through the verify + compact path)
     int sync_upload = 0;  // RJ_SYNC_UPLOAD: upload every input before the plan starts
+    int wide_carry = 1;   // RJ_TUNE_WIDE_CARRY: several payload columns of a side (and NULL-bearing ones) travel
+                          // with the key when they fit MAX_WORDS - KW carry words; 0: a row index travels and
+                          // every column is gathered afterwards (k_gather)
+    int fold_owner = 1;   // RJ_TUNE_FOLD_OWNER: a sharded join's stage A partitions by (owner rank, first local digit)
+                          // in one pass; 0: by owner rank only (stage B then runs one more pass)
+    int exchange_timeout_ms = 120000;  // RJ_EXCHANGE_TIMEOUT_MS: bound on every wait of the exchange step of a
+                                       // sharded join (communicator bring-up, count gathers, the all-to-all)
+    // RJ_DEBUG_SHARD_FAIL (tests): global rank RJ_DEBUG_SHARD_FAIL_RANK fails locally at this point of a
+    // sharded join — 1: while preparing, 2: in stage A, 3: allocating its receive buffers
+    int debug_shard_fail = 0, debug_shard_fail_rank = 0;
     void from_env();
 };
 
@@ -203,7 +213,7 @@ struct Context {
     // pinned staging for H2D / D2H of page images
     void*  pinned = nullptr;
     size_t pinned_bytes = 0;
-    static constexpr size_t SMALL_PINNED = 4096;
+    static constexpr size_t SMALL_PINNED = 16384;
     void*  pinned_small = nullptr;  // SMALL_PINNED bytes for counters that travel to the host
     void*  small_pinned();
     // second lane (rj_execute): inputs are uploaded by a helper thread on their own stream
@@ -232,6 +242,7 @@ struct Context {
     Context*               lane(int i) { return i == 0 ? this : peers[(size_t)i - 1]; }
     int   n_cu = 0;
     int   compute_units();  // CUs of the device (persistent-kernel grids)
+    void  prewarm();        // RJ_CTX_PREWARM: one-off set-up costs now instead of in the first rj_execute
     BufP  buf(size_t bytes) { return std::make_shared<Buf>(this, bytes ? bytes : 16); }
     void* staging(size_t bytes);
     void  sync() { RJ_HIP(hipStreamSynchronize(stream)); }

@@ -125,8 +125,15 @@ __device__ __forceinline__ uint64_t col_load64(const ColRef& c, uint32_t row) {
 }
 
 __device__ __forceinline__ void stream_store(const OutStream& o, uint64_t row, uint32_t lo,
-                                             uint32_t hi) {
+                                             uint32_t hi, uint32_t x2 = 0u) {
     switch (o.mode) {
+    case ST_DENSE96: {
+        uint32_t* r = reinterpret_cast<uint32_t*>(o.base) + row * 3u;
+        r[0] = lo;
+        r[1] = hi;
+        r[2] = x2;
+        break;
+    }
     case ST_DENSE32: reinterpret_cast<uint32_t*>(o.base)[row] = lo; break;
     case ST_DENSE64:
         reinterpret_cast<uint64_t*>(o.base)[row] = (uint64_t)lo | ((uint64_t)hi << 32);
@@ -277,22 +284,23 @@ __global__ __launch_bounds__(256) void k_decode_pages(const uint8_t* pages, cons
 // ==================================================================== K3 scan
 // Single workgroup of 1024 threads; thread t owns a contiguous chunk.
 // MODE 0: v[i] = in[i].  MODE 1: v[i] = ceil((in[i+1]-in[i]) / div)  (group table)
+// (in_end, MODE 1 only: segment i ends at in_end[i] instead of in[i + 1])
 template <int MODE>
-__global__ __launch_bounds__(1024) void k_scan_bins(const uint32_t* in, uint32_t n, uint32_t div,
-                                                    uint32_t* off, uint32_t* cursor) {
+__global__ __launch_bounds__(1024) void k_scan_bins(const uint32_t* in, const uint32_t* in_end, uint32_t n,
+                                                    uint32_t div, uint32_t* off, uint32_t* cursor) {
     __shared__ uint32_t s_wsum[16];
     const uint32_t      chunk = (n + 1023u) / 1024u;
     const uint32_t      b = threadIdx.x * chunk;
     const uint32_t      e = min(n, b + chunk);
     uint32_t            sum = 0;
     for (uint32_t i = b; i < e; ++i) {
-        uint32_t v = MODE == 0 ? in[i] : (in[i + 1] - in[i] + div - 1u) / div;
+        uint32_t v = MODE == 0 ? in[i] : ((in_end ? in_end[i] : in[i + 1]) - in[i] + div - 1u) / div;
         sum += v;
     }
     uint32_t total;
     uint32_t run = block_excl_scan(sum, s_wsum, total);
     for (uint32_t i = b; i < e; ++i) {
-        uint32_t v = MODE == 0 ? in[i] : (in[i + 1] - in[i] + div - 1u) / div;
+        uint32_t v = MODE == 0 ? in[i] : ((in_end ? in_end[i] : in[i + 1]) - in[i] + div - 1u) / div;
         off[i] = run;
         if (cursor) cursor[i] = run;
         run += v;
@@ -468,6 +476,36 @@ struct Aos3Loader {
     }
 };
 
+// Keys only out of 12-byte tuples (the histogram of a later pass when no digit side array was
+// written): every third word.  The lines are fetched whole either way — 12 bytes of HBM traffic
+// per tuple for 4 bytes of key — which pays only where the scatter behind it finds them cached.
+struct Aos3KeyLoader {
+    const uint32_t* in;
+    __device__ __forceinline__ uint32_t key_tile(uint32_t base, uint32_t end, uint32_t (&hk)[PT_ITEMS]) const {
+        if (base + PT_TILE <= end) {
+#pragma unroll
+            for (int v = 0; v < PT_ITEMS / 4; ++v) {
+                const uint32_t* p = in + (size_t)(base + (v * PT_THREADS + threadIdx.x) * 4) * 3;
+                const u32x4a    x = *reinterpret_cast<const u32x4a*>(p), y = *reinterpret_cast<const u32x4a*>(p + 4),
+                             z = *reinterpret_cast<const u32x4a*>(p + 8);
+                hk[4 * v + 0] = x[0];
+                hk[4 * v + 1] = x[3];
+                hk[4 * v + 2] = y[2];
+                hk[4 * v + 3] = z[1];
+            }
+            return PT_ALL_ITEMS;
+        }
+        uint32_t ok = 0;
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS; ++j) {
+            const uint32_t i = base + j * PT_THREADS + threadIdx.x;
+            hk[j] = in[(size_t)min(i, end - 1u) * 3];
+            ok |= (uint32_t)(i < end) << j;
+        }
+        return ok;
+    }
+};
+
 // The side array of 16-bit digits a 12-byte-tuple pass wrote for its successor: the histogram
 // of that successor reads 2 bytes per tuple.  key_tile hands the digit back in the bit position
 // the histogram kernel takes it from.
@@ -598,9 +636,13 @@ __device__ __forceinline__ uint64_t col_off64(bool paged, uint32_t row) {
 // Forms tuples straight from columns: page decode (regular pages), NULL-key
 // drop (reference src/execute.cpp:62-83: only rows whose variant holds KeyType
 // are valid) and hashing fused into the first radix pass.
-template <int KW, int CW>
+// WIDE (WideLayout): the carry is made of several columns — two or three 32-bit ones, or a
+// 64-bit one followed by a 32-bit one (CARRY_WIDE; a validity word, where some carried column
+// has NULLs, is one of the 32-bit columns by then: k_pack_validity).
+template <int KW, int CW, int WIDE = WIDE_NONE>
 struct SrcLoader {
     static constexpr bool kPrefetch = false;
+    static_assert(WIDE == WIDE_NONE || (WIDE == WIDE_32S && CW >= 2) || (WIDE == WIDE_64_32 && CW == 3), "wide carry layouts");
     TupleSrc s;
 
     // Row of item j.  Full tiles use the vector mapping (four consecutive rows per thread
@@ -640,6 +682,16 @@ struct SrcLoader {
                 const uint32_t ic = min(base + j * PT_THREADS + threadIdx.x, end - 1u);
                 out[j] = *reinterpret_cast<const uint32_t*>(p + col_off32(paged, ic));
             }
+        }
+    }
+    // a 32-bit column of any kind (a base table's row-id column included)
+    __device__ __forceinline__ static void load_col32_any(const ColRef& c, bool vec, uint32_t base, uint32_t end,
+                                                          uint32_t (&out)[PT_ITEMS]) {
+        if (c.kind == COL_IOTA) {
+#pragma unroll
+            for (int j = 0; j < PT_ITEMS; ++j) out[j] = item_row(vec, base, j);
+        } else {
+            load_col32(c, vec, base, end, out);
         }
     }
     template <bool NT = false>
@@ -742,7 +794,31 @@ struct SrcLoader {
         const bool vec = base + PT_TILE <= end;
         uint32_t   lo[PT_ITEMS], hi[PT_ITEMS];
         uint32_t   ok = raw_keys(vec, base, end, lo, hi);
-        if constexpr (CW >= 1) {
+        if constexpr (WIDE == WIDE_32S) {
+            uint32_t c0[PT_ITEMS];
+            load_col32_any(s.carry, vec, base, end, c0);
+#pragma unroll
+            for (int j = 0; j < PT_ITEMS; ++j) w[j][KW] = c0[j];
+            load_col32_any(s.carry2, vec, base, end, c0);
+#pragma unroll
+            for (int j = 0; j < PT_ITEMS; ++j) w[j][KW + 1] = c0[j];
+            if constexpr (CW == 3) {
+                load_col32_any(s.carry3, vec, base, end, c0);
+#pragma unroll
+                for (int j = 0; j < PT_ITEMS; ++j) w[j][KW + 2] = c0[j];
+            }
+        } else if constexpr (WIDE == WIDE_64_32) {
+            uint32_t c0[PT_ITEMS], c1[PT_ITEMS];
+            load_col64(s.carry, vec, base, end, c0, c1);
+#pragma unroll
+            for (int j = 0; j < PT_ITEMS; ++j) {
+                w[j][KW] = c0[j];
+                w[j][KW + 1] = c1[j];
+            }
+            load_col32_any(s.carry2, vec, base, end, c0);
+#pragma unroll
+            for (int j = 0; j < PT_ITEMS; ++j) w[j][KW + 2] = c0[j];
+        } else if constexpr (CW >= 1) {
             if (s.carry_mode == CARRY_ROWIDX) {  // CW == 1 by construction
 #pragma unroll
                 for (int j = 0; j < PT_ITEMS; ++j) w[j][KW] = item_row(vec, base, j);
@@ -800,11 +876,11 @@ __device__ __forceinline__ bool group_range(const PassParams& pp, uint32_t g, ui
         else
             hi = mid;
     }
-    seg = lo;
+    seg = lo >> pp.oseg_shift;  // the OUTPUT segment (bins, cursors) input segment `lo` feeds
     uint32_t gi = g - pp.grp_start[lo];
     uint64_t b = (uint64_t)pp.seg_off[lo] + (uint64_t)gi * gt;
     begin = (uint32_t)b;
-    end = (uint32_t)min((uint64_t)pp.seg_off[lo + 1], b + gt);
+    end = (uint32_t)min((uint64_t)(pp.seg_end ? pp.seg_end[lo] : pp.seg_off[lo + 1]), b + gt);
     return begin < end;
 }
 
@@ -834,11 +910,11 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_hist(Loader ld, PassParams 
             ok = ld.key_tile(base, end, hk);
 #pragma unroll
         for (int j = 0; j < PT_ITEMS; ++j)
-            if ((ok >> j) & 1u) atomicAdd(&s_h[(hk[j] >> pp.shift) & mask], 1u);
+            if ((ok >> j) & 1u) atomicAdd(&s_h[pass_digit(pp, hk[j], mask)], 1u);
     }
     if constexpr (loader_needs_begin<Loader>::value) {
         uint32_t hx;
-        if (ld.extra(begin, end, hx)) atomicAdd(&s_h[(hx >> pp.shift) & mask], 1u);
+        if (ld.extra(begin, end, hx)) atomicAdd(&s_h[pass_digit(pp, hx, mask)], 1u);
     }
     lds_barrier();
     for (uint32_t d = threadIdx.x; d < F; d += PT_THREADS) {
@@ -1013,7 +1089,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassPara
         for (int j = 0; j < PT_ITEMS; ++j) {
             dr[j] = 0xffffffffu;
             if ((ok >> j) & 1u) {
-                uint32_t d = (w[j][0] >> pp.shift) & mask;
+                uint32_t d = pass_digit(pp, w[j][0], mask);
                 uint32_t r = atomicAdd(&s_cnt[d], 1u);
                 dr[j] = (d << 16) | r;
             }
@@ -1059,7 +1135,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassPara
                     if (gi < total) {
                         const uint32_t v = s_k[i];
                         const uint2    c = s_p[i];
-                        const uint32_t g = s_delta[(v >> pp.shift) & mask] + gi;
+                        const uint32_t g = s_delta[pass_digit(pp, v, mask)] + gi;
                         uint32_t*      o = out.w[0] + (size_t)g * 3u;
                         o[0] = v;
                         o[1] = c.x;
@@ -1086,7 +1162,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassPara
             dest[k] = 0;
             if (i < total) {
                 const uint32_t v = s_stage[i];
-                dest[k] = s_delta[(v >> pp.shift) & mask] + i;
+                dest[k] = s_delta[pass_digit(pp, v, mask)] + i;
                 out.w[0][dest[k]] = v;
             }
         }
@@ -1159,7 +1235,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter_packed(Loader ld, P
         for (int j = 0; j < PT_ITEMS; ++j) {
             dr[j] = 0xffffffffu;
             if ((ok >> j) & 1u) {
-                uint32_t d = (w[j][0] >> pp.shift) & mask;
+                uint32_t d = pass_digit(pp, w[j][0], mask);
                 uint32_t r = atomicAdd(&s_cnt[d], 1u);
                 dr[j] = (d << 16) | r;
             }
@@ -1190,7 +1266,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter_packed(Loader ld, P
             const uint32_t i = k * PT_THREADS + threadIdx.x;
             if (i < total) {
                 const uint2    v = s_stage[i];
-                const uint32_t g = s_delta[(v.x >> pp.shift) & mask] + i;
+                const uint32_t g = s_delta[pass_digit(pp, v.x, mask)] + i;
                 out[g] = v;
                 if (pp.side_out) pp.side_out[g] = (uint16_t)((v.x >> pp.next_shift) & pp.next_mask);
             }
@@ -1405,7 +1481,7 @@ __global__ __launch_bounds__(jn_threads(TG ? 2 : KW + CWR), jn_min_waves(TG ? 2 
                 return;
             }
         }
-        constexpr int NA = CWR == 2 ? KW : LW;  // plain word arrays; a two-word carry is a pair array
+        constexpr int NA = CWR >= 2 ? KW + CWR - 2 : LW;  // plain word arrays; the last two carry words are a pair array
 #pragma unroll
         for (int v = 0; v < RPT / 4; ++v) {
             const uint32_t i0 = (v * TH + threadIdx.x) * 4;
@@ -1416,17 +1492,17 @@ __global__ __launch_bounds__(jn_threads(TG ? 2 : KW + CWR), jn_min_waves(TG ? 2 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) rw[4 * v + e][a] = x[e];
                 }
-                if constexpr (CWR == 2) {
-                    const uint32_t* p2 = jp.R.w[KW] + ((size_t)rc + i0) * 2;
+                if constexpr (CWR >= 2) {
+                    const uint32_t* p2 = jp.R.w[NA] + ((size_t)rc + i0) * 2;
                     u32x4a x = *reinterpret_cast<const u32x4a*>(p2), y = *reinterpret_cast<const u32x4a*>(p2 + 4);
-                    rw[4 * v + 0][KW] = x[0];
-                    rw[4 * v + 0][KW + 1] = x[1];
-                    rw[4 * v + 1][KW] = x[2];
-                    rw[4 * v + 1][KW + 1] = x[3];
-                    rw[4 * v + 2][KW] = y[0];
-                    rw[4 * v + 2][KW + 1] = y[1];
-                    rw[4 * v + 3][KW] = y[2];
-                    rw[4 * v + 3][KW + 1] = y[3];
+                    rw[4 * v + 0][NA] = x[0];
+                    rw[4 * v + 0][NA + 1] = x[1];
+                    rw[4 * v + 1][NA] = x[2];
+                    rw[4 * v + 1][NA + 1] = x[3];
+                    rw[4 * v + 2][NA] = y[0];
+                    rw[4 * v + 2][NA + 1] = y[1];
+                    rw[4 * v + 3][NA] = y[2];
+                    rw[4 * v + 3][NA + 1] = y[3];
                 }
             } else {
 #pragma unroll
@@ -1434,11 +1510,11 @@ __global__ __launch_bounds__(jn_threads(TG ? 2 : KW + CWR), jn_min_waves(TG ? 2 
 #pragma unroll
                     for (int a = 0; a < NA; ++a)
                         rw[4 * v + e][a] = i0 + e < rn ? jp.R.w[a][rc + i0 + e] : 0u;
-                    if constexpr (CWR == 2) {
-                        uint2 t = i0 + e < rn ? reinterpret_cast<const uint2*>(jp.R.w[KW])[rc + i0 + e]
+                    if constexpr (CWR >= 2) {
+                        uint2 t = i0 + e < rn ? reinterpret_cast<const uint2*>(jp.R.w[NA])[rc + i0 + e]
                                               : make_uint2(0u, 0u);
-                        rw[4 * v + e][KW] = t.x;
-                        rw[4 * v + e][KW + 1] = t.y;
+                        rw[4 * v + e][NA] = t.x;
+                        rw[4 * v + e][NA + 1] = t.y;
                     }
                 }
             }
@@ -1473,7 +1549,7 @@ __global__ __launch_bounds__(jn_threads(TG ? 2 : KW + CWR), jn_min_waves(TG ? 2 
                 return;
             }
         }
-        constexpr int NA = CWS == 2 ? KW : SW;  // plain word arrays; a two-word carry is a pair array
+        constexpr int NA = CWS >= 2 ? KW + CWS - 2 : SW;  // plain word arrays; the last two carry words are a pair array
 #pragma unroll
         for (int v = 0; v < SPT / 4; ++v) {
             const uint32_t i0 = (v * TH + threadIdx.x) * 4;
@@ -1484,17 +1560,17 @@ __global__ __launch_bounds__(jn_threads(TG ? 2 : KW + CWR), jn_min_waves(TG ? 2 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) sw[4 * v + e][a] = x[e];
                 }
-                if constexpr (CWS == 2) {
-                    const uint32_t* p2 = jp.S.w[KW] + ((size_t)sc + i0) * 2;
+                if constexpr (CWS >= 2) {
+                    const uint32_t* p2 = jp.S.w[NA] + ((size_t)sc + i0) * 2;
                     u32x4a x = *reinterpret_cast<const u32x4a*>(p2), y = *reinterpret_cast<const u32x4a*>(p2 + 4);
-                    sw[4 * v + 0][KW] = x[0];
-                    sw[4 * v + 0][KW + 1] = x[1];
-                    sw[4 * v + 1][KW] = x[2];
-                    sw[4 * v + 1][KW + 1] = x[3];
-                    sw[4 * v + 2][KW] = y[0];
-                    sw[4 * v + 2][KW + 1] = y[1];
-                    sw[4 * v + 3][KW] = y[2];
-                    sw[4 * v + 3][KW + 1] = y[3];
+                    sw[4 * v + 0][NA] = x[0];
+                    sw[4 * v + 0][NA + 1] = x[1];
+                    sw[4 * v + 1][NA] = x[2];
+                    sw[4 * v + 1][NA + 1] = x[3];
+                    sw[4 * v + 2][NA] = y[0];
+                    sw[4 * v + 2][NA + 1] = y[1];
+                    sw[4 * v + 3][NA] = y[2];
+                    sw[4 * v + 3][NA + 1] = y[3];
                 }
             } else {
 #pragma unroll
@@ -1502,11 +1578,11 @@ __global__ __launch_bounds__(jn_threads(TG ? 2 : KW + CWR), jn_min_waves(TG ? 2 
 #pragma unroll
                     for (int a = 0; a < NA; ++a)
                         sw[4 * v + e][a] = i0 + e < sn ? jp.S.w[a][sc + i0 + e] : 0u;
-                    if constexpr (CWS == 2) {
-                        uint2 t = i0 + e < sn ? reinterpret_cast<const uint2*>(jp.S.w[KW])[sc + i0 + e]
+                    if constexpr (CWS >= 2) {
+                        uint2 t = i0 + e < sn ? reinterpret_cast<const uint2*>(jp.S.w[NA])[sc + i0 + e]
                                               : make_uint2(0u, 0u);
-                        sw[4 * v + e][KW] = t.x;
-                        sw[4 * v + e][KW + 1] = t.y;
+                        sw[4 * v + e][NA] = t.x;
+                        sw[4 * v + e][NA + 1] = t.y;
                     }
                 }
             }
@@ -1514,7 +1590,7 @@ __global__ __launch_bounds__(jn_threads(TG ? 2 : KW + CWR), jn_min_waves(TG ? 2 
     };
     // one output row: key + build carry + probe carry
     auto emit_row = [&](uint64_t row, uint32_t klo, uint32_t khi, uint32_t b0, uint32_t b1,
-                        uint32_t p0, uint32_t p1) {
+                        uint32_t p0, uint32_t p1, uint32_t b2 = 0u, uint32_t p2 = 0u) {
         if constexpr (OM == OM_PAGED32) {
             // one page/slot computation serves all three streams
             uint32_t r = (uint32_t)row, p = r / ROWS32;
@@ -1535,8 +1611,8 @@ __global__ __launch_bounds__(jn_threads(TG ? 2 : KW + CWR), jn_min_waves(TG ? 2 
             if constexpr (CWS >= 1) reinterpret_cast<uint32_t*>(jp.pc.base)[row] = p0;
         } else {
             stream_store(jp.key, row, klo, khi);
-            if constexpr (CWR >= 1) stream_store(jp.bc, row, b0, b1);
-            if constexpr (CWS >= 1) stream_store(jp.pc, row, p0, p1);
+            if constexpr (CWR >= 1) stream_store(jp.bc, row, b0, b1, b2);
+            if constexpr (CWS >= 1) stream_store(jp.pc, row, p0, p1, p2);
         }
     };
 
@@ -1723,14 +1799,15 @@ __global__ __launch_bounds__(jn_threads(TG ? 2 : KW + CWR), jn_min_waves(TG ? 2 
                     // the build carry of a tuple's FIRST match sits at the remembered slot
                     // f[j]: issue those reads for all tuples before the first store
                     // (TG reads them row by row instead: its registers are spoken for)
-                    uint32_t c0[TG ? 1 : SPT], c1[TG ? 1 : SPT];
+                    uint32_t c0[TG ? 1 : SPT], c1[TG ? 1 : SPT], c2[CWR == 3 ? SPT : 1];
                     if constexpr (!TG) {
 #pragma unroll
                         for (int j = 0; j < SPT; ++j) {
                             c0[j] = 0;
                             c1[j] = 0;
                             if constexpr (CWR >= 1) c0[j] = m[j] ? t_w[KW][f[j]] : 0u;
-                            if constexpr (CWR == 2) c1[j] = m[j] ? t_w[KW + 1][f[j]] : 0u;
+                            if constexpr (CWR >= 2) c1[j] = m[j] ? t_w[KW + 1][f[j]] : 0u;
+                            if constexpr (CWR == 3) c2[j] = m[j] ? t_w[KW + 2][f[j]] : 0u;
                         }
                     }
 #pragma unroll
@@ -1747,12 +1824,13 @@ __global__ __launch_bounds__(jn_threads(TG ? 2 : KW + CWR), jn_min_waves(TG ? 2 
                             khi = (uint32_t)(k64 >> 32);
                         }
                         const uint32_t p0 = CWS >= 1 ? sw[j][KW < SW ? KW : 0] : 0u;
-                        const uint32_t p1 = CWS == 2 ? sw[j][SW - 1] : 0u;
+                        const uint32_t p1 = CWS >= 2 ? sw[j][KW + 1 < SW ? KW + 1 : 0] : 0u;
+                        const uint32_t p2 = CWS == 3 ? sw[j][SW - 1] : 0u;
                         if constexpr (TG) {
                             const uint2 c = t_c2[f[j]];
-                            emit_row(row, klo, khi, c.x, c.y, p0, p1);
+                            emit_row(row, klo, khi, c.x, c.y, p0, p1, 0u, p2);
                         } else {
-                            emit_row(row, klo, khi, c0[j], c1[j], p0, p1);
+                            emit_row(row, klo, khi, c0[j], c1[j], p0, p1, CWR == 3 ? c2[CWR == 3 ? j : 0] : 0u, p2);
                         }
                         if constexpr (TG) {
                             // duplicates of the build key (rare): walk the buckets again from the
@@ -1769,7 +1847,7 @@ __global__ __launch_bounds__(jn_threads(TG ? 2 : KW + CWR), jn_min_waves(TG ? 2 
                                             if (left != m[j]) {  // the first match went out above
                                                 ++row;
                                                 const uint2 c = t_c2[sv[e] >> TGB];
-                                                emit_row(row, klo, khi, c.x, c.y, p0, p1);
+                                                emit_row(row, klo, khi, c.x, c.y, p0, p1, 0u, p2);
                                             }
                                             --left;
                                         }
@@ -1787,10 +1865,11 @@ __global__ __launch_bounds__(jn_threads(TG ? 2 : KW + CWR), jn_min_waves(TG ? 2 
                             if (KW == 2) eq = eq && t_w[KW - 1][slot] == sw[j][KW - 1];
                             if (eq) {
                                 ++row;
-                                uint32_t b0 = 0, b1 = 0;
+                                uint32_t b0 = 0, b1 = 0, b2 = 0;
                                 if constexpr (CWR >= 1) b0 = t_w[KW][slot];
-                                if constexpr (CWR == 2) b1 = t_w[KW + 1][slot];
-                                emit_row(row, klo, khi, b0, b1, p0, p1);
+                                if constexpr (CWR >= 2) b1 = t_w[KW + 1][slot];
+                                if constexpr (CWR == 3) b2 = t_w[KW + 2][slot];
+                                emit_row(row, klo, khi, b0, b1, p0, p1, b2, p2);
                                 --left;
                             }
                             slot = (slot + 1) & SMASK;
@@ -1838,10 +1917,23 @@ __device__ __forceinline__ bool src_key(const TupleSrc& s, uint32_t row, uint32_
     return ok;
 }
 template <int CW>
-__device__ __forceinline__ void src_carry(const TupleSrc& s, uint32_t row, uint32_t& c0, uint32_t& c1) {
-    c0 = c1 = 0;
+__device__ __forceinline__ void src_carry(const TupleSrc& s, uint32_t row, uint32_t& c0, uint32_t& c1, uint32_t& c2) {
+    c0 = c1 = c2 = 0;
     if constexpr (CW >= 1) {
-        if (s.carry_mode == CARRY_ROWIDX) {
+        if (s.carry_mode == CARRY_WIDE) {
+            if constexpr (CW >= 2) {
+                if (s.wide == WIDE_64_32) {
+                    const uint64_t v = col_load64(s.carry, row);
+                    c0 = (uint32_t)v;
+                    c1 = (uint32_t)(v >> 32);
+                    c2 = col_load32(s.carry2, row);
+                } else {
+                    c0 = col_load32(s.carry, row);
+                    c1 = col_load32(s.carry2, row);
+                    if constexpr (CW == 3) c2 = col_load32(s.carry3, row);
+                }
+            }
+        } else if (s.carry_mode == CARRY_ROWIDX) {
             c0 = row;
         } else if constexpr (CW == 1) {
             c0 = col_load32(s.carry, row);
@@ -1973,8 +2065,8 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_bcast(BcastParams bp) {
                     k0 = (uint32_t)k64;
                     k1 = (uint32_t)(k64 >> 32);
                 }
-                uint32_t p0, p1;
-                src_carry<CWS>(bp.S, srow, p0, p1);
+                uint32_t p0, p1, p2;
+                src_carry<CWS>(bp.S, srow, p0, p1, p2);
                 uint32_t b = klo[j] & BMASK;
                 bool     more;
                 do {
@@ -1982,11 +2074,11 @@ __global__ __launch_bounds__(JN_THREADS) void k_join_bcast(BcastParams bp) {
                     while (eq) {
                         const uint32_t slot = b * 4 + (uint32_t)__builtin_ctz(eq);
                         eq &= eq - 1;
-                        uint32_t b0, b1;
-                        src_carry<CWR>(bp.R, t_w[KW][slot], b0, b1);
+                        uint32_t b0, b1, b2;
+                        src_carry<CWR>(bp.R, t_w[KW][slot], b0, b1, b2);
                         stream_store(bp.key, row, k0, k1);
-                        if constexpr (CWR >= 1) stream_store(bp.bc, row, b0, b1);
-                        if constexpr (CWS >= 1) stream_store(bp.pc, row, p0, p1);
+                        if constexpr (CWR >= 1) stream_store(bp.bc, row, b0, b1, b2);
+                        if constexpr (CWS >= 1) stream_store(bp.pc, row, p0, p1, p2);
                         ++row;
                     }
                     b = (b + 1) & BMASK;
@@ -2131,6 +2223,36 @@ __global__ __launch_bounds__(256) void k_encode_nullable(const uint8_t* values, 
     }
 }
 
+// ============================================================ wide carries
+// Validity of up to three carried columns as ONE 32-bit word per row (bit c = column c is
+// non-NULL): the word then travels like a 32-bit column of the wide carry.
+__global__ __launch_bounds__(256) void k_pack_validity(const uint8_t* v0, const uint8_t* v1, const uint8_t* v2,
+                                                       uint32_t n, uint32_t* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = (uint32_t)(!v0 || v0[i]) | ((uint32_t)(!v1 || v1[i]) << 1) | ((uint32_t)(!v2 || v2[i]) << 2);
+}
+
+// The records a join emitted for a wide carry (cw words per output row) -> one dense array per
+// carried column, plus validity bytes for the columns that have them.  Sequential reads and
+// writes: this replaces k_gather's random reads through a row-index stream.
+__global__ __launch_bounds__(256) void k_split_records(SplitParams sp, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* r = sp.rec + i * sp.cw;
+    const uint32_t  vw = sp.valid_word >= 0 ? r[sp.valid_word] : 0xffffffffu;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if (c >= sp.n_cols) break;
+        const uint32_t lo = r[sp.col[c].word];
+        if (sp.col[c].width == 8)
+            reinterpret_cast<uint64_t*>(sp.col[c].out)[i] = (uint64_t)lo | ((uint64_t)r[sp.col[c].word + 1] << 32);
+        else
+            reinterpret_cast<uint32_t*>(sp.col[c].out)[i] = lo;
+        if (sp.col[c].valid) sp.col[c].valid[i] = (uint8_t)((vw >> sp.col[c].valid_bit) & 1u);
+    }
+}
+
 // ================================================================== launchers
 // A rejected launch (LDS or launch-bounds mismatch of a tuning variant, wrong device) must not
 // pass silently: the stream would "succeed" and the join return stale buffers with RJ_OK.
@@ -2174,7 +2296,7 @@ void launch_decode_pages(const Launch& L, const uint8_t* pages, uint32_t n_pages
 
 void launch_scan_bins(const Launch& L, const uint32_t* in, uint32_t n, uint32_t* off,
                       uint32_t* cursor) {
-    RJ_KLAUNCH(L, "scan_bins", (k_scan_bins<0>), 1, 1024, in, n, 1u, off, cursor);
+    RJ_KLAUNCH(L, "scan_bins", (k_scan_bins<0>), 1, 1024, in, (const uint32_t*)nullptr, n, 1u, off, cursor);
 }
 
 void launch_scan_segments(const Launch& L, const uint32_t* hist, const uint32_t* seg_off,
@@ -2184,8 +2306,8 @@ void launch_scan_segments(const Launch& L, const uint32_t* hist, const uint32_t*
 }
 
 void launch_group_table(const Launch& L, const uint32_t* seg_off, uint32_t nseg,
-                        uint32_t group_tuples, uint32_t* grp_start) {
-    RJ_KLAUNCH(L, "group_table", (k_scan_bins<1>), 1, 1024, seg_off, nseg, group_tuples, grp_start,
+                        uint32_t group_tuples, uint32_t* grp_start, const uint32_t* seg_end) {
+    RJ_KLAUNCH(L, "group_table", (k_scan_bins<1>), 1, 1024, seg_off, seg_end, nseg, group_tuples, grp_start,
                (uint32_t*)nullptr);
 }
 
@@ -2238,21 +2360,38 @@ void launch_scan_fine(const Launch& L, const uint32_t* fine, uint32_t F1, uint32
                coarse_x);
 }
 
-template <int KW, int CW>
+// (carries of two or more words: the last two travel as one array of 8-byte pairs)
+template <int KW, int CW, int WIDE = WIDE_NONE>
 static void scatter_src_t(const Launch& L, const TupleSrc& src, const PassParams& pp,
                           uint32_t n_groups, const Words& out) {
-    SrcLoader<KW, CW> ld{src};
-    RJ_KLAUNCH(L, "pass1_scatter", (k_pass_scatter<KW + CW, SrcLoader<KW, CW>, (CW == 2 ? KW : -1), false>),
+    SrcLoader<KW, CW, WIDE> ld{src};
+    RJ_KLAUNCH(L, "pass1_scatter", (k_pass_scatter<KW + CW, SrcLoader<KW, CW, WIDE>, (CW >= 2 ? KW + CW - 2 : -1), false>),
                n_groups, PT_THREADS, ld, pp, out);
 }
 
 void launch_pass_scatter_src(const Launch& L, const TupleSrc& src, int key_words, int carry_words,
                              const PassParams& pp, uint32_t n_groups, const Words& out, bool aos3) {
     if (!n_groups) return;
+    const int wide = src.carry_mode == CARRY_WIDE ? src.wide : WIDE_NONE;
     if (aos3) {
         if (key_words != 1 || carry_words != 2) launch_failed("pass1_scatter", "12-byte tuples need KW=1, CW=2", true);
+        if (wide == WIDE_32S) {
+            SrcLoader<1, 2, WIDE_32S> ld{src};
+            RJ_KLAUNCH(L, "pass1_scatter", (k_pass_scatter<3, SrcLoader<1, 2, WIDE_32S>, 1, true>), n_groups, PT_THREADS, ld, pp, out);
+            return;
+        }
         SrcLoader<1, 2> ld{src};
         RJ_KLAUNCH(L, "pass1_scatter", (k_pass_scatter<3, SrcLoader<1, 2>, 1, true>), n_groups, PT_THREADS, ld, pp, out);
+        return;
+    }
+    if (wide != WIDE_NONE) {
+        switch (key_words * 100 + carry_words * 10 + wide) {
+        case 121: scatter_src_t<1, 2, WIDE_32S>(L, src, pp, n_groups, out); break;
+        case 131: scatter_src_t<1, 3, WIDE_32S>(L, src, pp, n_groups, out); break;
+        case 132: scatter_src_t<1, 3, WIDE_64_32>(L, src, pp, n_groups, out); break;
+        case 221: scatter_src_t<2, 2, WIDE_32S>(L, src, pp, n_groups, out); break;
+        default: launch_failed("pass1_scatter", "no kernel for this wide carry layout", true);
+        }
         return;
     }
     switch (key_words * 10 + carry_words) {
@@ -2311,6 +2450,11 @@ void launch_pass_hist_digits(const Launch& L, const uint16_t* digits, const Pass
     if (!n_groups) return;
     DigitLoader ld{digits, pp.shift};
     RJ_KLAUNCH(L, "pass2_hist", (k_pass_hist<DigitLoader>), n_groups, PT_THREADS, ld, pp);
+}
+
+void launch_pass_hist_aos3(const Launch& L, const uint32_t* in_tuples, const PassParams& pp, uint32_t n_groups) {
+    if (!n_groups) return;
+    RJ_KLAUNCH(L, "pass2_hist", (k_pass_hist<Aos3KeyLoader>), n_groups, PT_THREADS, Aos3KeyLoader{in_tuples}, pp);
 }
 
 void launch_pass_scatter_aos3(const Launch& L, const uint32_t* in_tuples, const PassParams& pp, uint32_t n_groups,
@@ -2445,6 +2589,13 @@ void launch_join(const Launch& L, int key_words, int cw_build, int cw_probe, con
     case 120: join_t<1, 2, 0>(L, jp, grid); break;
     case 121: join_t<1, 2, 1>(L, jp, grid); break;
     case 122: join_t<1, 2, 2>(L, jp, grid); break;
+    case 103: join_t<1, 0, 3>(L, jp, grid); break;  // three-word (wide) carries
+    case 113: join_t<1, 1, 3>(L, jp, grid); break;
+    case 123: join_t<1, 2, 3>(L, jp, grid); break;
+    case 130: join_t<1, 3, 0>(L, jp, grid); break;
+    case 131: join_t<1, 3, 1>(L, jp, grid); break;
+    case 132: join_t<1, 3, 2>(L, jp, grid); break;
+    case 133: join_t<1, 3, 3>(L, jp, grid); break;
     case 200: join_t<2, 0, 0>(L, jp, grid); break;
     case 201: join_t<2, 0, 1>(L, jp, grid); break;
     case 202: join_t<2, 0, 2>(L, jp, grid); break;
@@ -2476,6 +2627,13 @@ void launch_join_bcast(const Launch& L, int key_words, int cw_build, int cw_prob
     case 120: join_bcast_t<1, 2, 0>(L, bp, grid); break;
     case 121: join_bcast_t<1, 2, 1>(L, bp, grid); break;
     case 122: join_bcast_t<1, 2, 2>(L, bp, grid); break;
+    case 103: join_bcast_t<1, 0, 3>(L, bp, grid); break;
+    case 113: join_bcast_t<1, 1, 3>(L, bp, grid); break;
+    case 123: join_bcast_t<1, 2, 3>(L, bp, grid); break;
+    case 130: join_bcast_t<1, 3, 0>(L, bp, grid); break;
+    case 131: join_bcast_t<1, 3, 1>(L, bp, grid); break;
+    case 132: join_bcast_t<1, 3, 2>(L, bp, grid); break;
+    case 133: join_bcast_t<1, 3, 3>(L, bp, grid); break;
     case 200: join_bcast_t<2, 0, 0>(L, bp, grid); break;
     case 201: join_bcast_t<2, 0, 1>(L, bp, grid); break;
     case 202: join_bcast_t<2, 0, 2>(L, bp, grid); break;
@@ -2487,6 +2645,17 @@ void launch_join_bcast(const Launch& L, int key_words, int cw_build, int cw_prob
     case 222: join_bcast_t<2, 2, 2>(L, bp, grid); break;
     default: launch_failed("join_broadcast", "no kernel for this key/carry word count", true);
     }
+}
+
+void launch_pack_validity(const Launch& L, const uint8_t* v0, const uint8_t* v1, const uint8_t* v2, uint32_t n,
+                          uint32_t* out) {
+    if (!n) return;
+    RJ_KLAUNCH(L, "pack_validity", k_pack_validity, (n + 255) / 256, 256, v0, v1, v2, n, out);
+}
+
+void launch_split_records(const Launch& L, const SplitParams& sp, uint64_t n) {
+    if (!n) return;
+    RJ_KLAUNCH(L, "split_records", k_split_records, (uint32_t)((n + 255) / 256), 256, sp, n);
 }
 
 void launch_gather(const Launch& L, const ColRef& src, const uint32_t* idx, uint64_t n,

@@ -40,9 +40,10 @@ void launch_scan_bins(const Launch& L, const uint32_t* in, uint32_t n, uint32_t*
 // per-segment scan: off[seg*F+d] = seg_off[seg] + prefix of hist[seg][0..d); off[nseg*F] = total
 void launch_scan_segments(const Launch& L, const uint32_t* hist, const uint32_t* seg_off,
                           uint32_t nseg, uint32_t F, uint32_t xcd_log2, uint32_t* off, uint32_t* cursor);
-// grp_start[s] = sum_{t<s} ceil(len_t / group_tuples) over segments (seg_off[nseg+1])
+// grp_start[s] = sum_{t<s} ceil(len_t / group_tuples) over segments (seg_off[nseg+1]; with seg_end,
+// segment t is [seg_off[t], seg_end[t]) and seg_off needs only nseg entries)
 void launch_group_table(const Launch& L, const uint32_t* seg_off, uint32_t nseg,
-                        uint32_t group_tuples, uint32_t* grp_start);
+                        uint32_t group_tuples, uint32_t* grp_start, const uint32_t* seg_end = nullptr);
 
 // ---- radix partition pass (replaces the ≤128-way hash partition of row indices,
 //      reference src/execute.cpp:124-184)
@@ -82,6 +83,8 @@ void launch_pass_scatter_dense(const Launch& L, const Words& in, int n_words, in
 // pass reads the 16-bit digit side array its predecessor wrote (PassParams::side_out), the
 // scatter reads and writes 12-byte tuples
 void launch_pass_hist_digits(const Launch& L, const uint16_t* digits, const PassParams& pp, uint32_t n_groups);
+// ... or, without a side array, fishes the keys out of the 12-byte tuples themselves
+void launch_pass_hist_aos3(const Launch& L, const uint32_t* in_tuples, const PassParams& pp, uint32_t n_groups);
 void launch_pass_scatter_aos3(const Launch& L, const uint32_t* in_tuples, const PassParams& pp, uint32_t n_groups,
                               uint32_t* out_tuples);
 
@@ -110,6 +113,11 @@ void launch_join_bcast(const Launch& L, int key_words, int cw_build, int cw_prob
 //      and Table::to_columnar, src/build_table.cpp:456-594)
 void launch_gather(const Launch& L, const ColRef& src, const uint32_t* idx, uint64_t n,
                    const OutStream& dst, uint8_t* dst_valid);
+// wide carries (several payload columns travelling with the key): validity bits of up to three
+// columns as one word per row; the emitted records -> one dense array (+ validity bytes) per column
+void launch_pack_validity(const Launch& L, const uint8_t* v0, const uint8_t* v1, const uint8_t* v2, uint32_t n,
+                          uint32_t* out);
+void launch_split_records(const Launch& L, const SplitParams& sp, uint64_t n);
 void launch_finish_pages(const Launch& L, uint8_t* pages, uint64_t n_rows, int width);
 // headers + bitmaps of up to three probe-written streams, row count read on the device
 void launch_finish_streams(const Launch& L, uint8_t* const* pages, const int* widths, uint32_t n,
@@ -133,6 +141,7 @@ void launch_vc_compact(const Launch& L, const uint8_t* keep, const uint32_t* bid
                        uint32_t* out_b, uint32_t* out_p, unsigned long long* cursor);
 // page_out == nullptr: pages_in_chunk[c] = pages of chunk c; else the pages are written to
 // page_out[page_base[c] ...]
+void prewarm_varchar_dev(const Launch& L, uint32_t* zeroed);  // (RJ_CTX_PREWARM: loads the code object)
 void launch_vc_walk(const Launch& L, const VcRow* rows, uint32_t n, uint32_t* pages_in_chunk,
                     const uint32_t* page_base, VcPage* page_out);
 void launch_vc_encode(const Launch& L, const uint8_t* pages, uint32_t n_pages, const VcRow* rows,

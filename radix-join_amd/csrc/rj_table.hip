@@ -491,6 +491,12 @@ Result* execute_host_sharded(Context* g, const rj_plan* plan, const std::vector<
     // columns alike (the two page capacities are coprime), so a shard is a sub-range of every
     // column's page pointers.
     constexpr uint64_t U = (uint64_t)ROWS32 * ROWS64;
+    // inputs below nl cut units would land on the last rank alone (every other shard empty) and
+    // still pay the uploads, the gathers and the exchange: such plans run on the first device
+    uint64_t largest = 0;
+    for (uint64_t i = 0; i < plan->n_inputs; ++i)
+        if (used[i]) largest = std::max<uint64_t>(largest, plan->inputs[i].num_rows);
+    if (largest < (uint64_t)nl * U) return nullptr;
     std::vector<std::vector<std::unique_ptr<Table>>> tabs((size_t)nl);
     std::vector<Table*>                              flat((size_t)nl * plan->n_inputs, nullptr);
     std::vector<std::vector<rj_column>>              views;  // keep the column views alive

@@ -11,8 +11,10 @@
 //                            array, the layout of build_table.cpp:406-427 / long-string
 //                            pages :384-405) -> pages with the fill rule of
 //                            Table::to_columnar (reference src/build_table.cpp:595-677) /
-//                            ColumnInserter<string> (reference include/plan.h:301-334),
-//                            in parallel slabs.
+//                            ColumnInserter<string> (reference include/plan.h:301-334):
+//                            lookup (parallel) -> page boundaries (the fill rule as counter
+//                            arithmetic) -> every page written in place (parallel), the
+//                            shape of the device encoder in rj_varchar_dev.hip.
 #include <algorithm>
 #include <cstring>
 
@@ -77,150 +79,138 @@ inline uint32_t popcount_below(const uint8_t* bitmap, uint32_t i) {
     return c;
 }
 
-struct Lookup {
-    const uint8_t* const*        pages;
-    uint64_t                     n_pages;
-    const std::vector<uint64_t>& row_base;
-    std::string                  scratch;  // long strings are stitched here
+// One result row after the lookup: where its characters sit.  Short strings point into the source
+// page; a long string (0xffff / 0xfffe page chain) names the first page of its chain.
+struct StrRef {
+    const char* p = nullptr;
+    uint32_t    len = 0;        // characters; NULL_LEN = NULL row
+    uint32_t    chain = 0;      // long string: index of its 0xffff page + 1, else 0
+};
+constexpr uint32_t NULL_LEN = 0xffffffffu;
 
-    // -> false for NULL; otherwise [*p, *p + *len) holds the string until the next call
-    bool get(uint64_t row, const char** p, uint32_t* len) {
-        if (row >= row_base[n_pages]) return false;  // rows the pages do not cover are NULL
-        uint64_t pg = (uint64_t)(std::upper_bound(row_base.begin(), row_base.end(), row) -
-                                 row_base.begin()) - 1;
-        const uint8_t* page = pages[pg];
-        uint16_t       nr = rd16(page);
-        if (nr == 0xffff) {
-            scratch.assign(reinterpret_cast<const char*>(page + 4), rd16(page + 2));
-            for (uint64_t q = pg + 1; q < n_pages && rd16(pages[q]) == 0xfffe; ++q)
-                scratch.append(reinterpret_cast<const char*>(pages[q] + 4), rd16(pages[q] + 2));
-            *p = scratch.data();
-            *len = (uint32_t)scratch.size();
-            return true;
-        }
-        uint32_t       i = (uint32_t)(row - row_base[pg]);
-        const uint8_t* bitmap = page + PAGE_BYTES - (nr + 7) / 8;
-        if (!((bitmap[i >> 3] >> (i & 7)) & 1)) return false;
-        uint32_t       idx = popcount_below(bitmap, i);
-        uint16_t       nnn = rd16(page + 2);
-        const uint8_t* offs = page + 4;
-        const char*    data = reinterpret_cast<const char*>(page) + 4 + (size_t)nnn * 2;
-        uint32_t       end = rd16(offs + (size_t)idx * 2);
-        uint32_t       beg = idx ? rd16(offs + (size_t)(idx - 1) * 2) : 0;
-        *p = data + beg;
-        *len = end - beg;
-        return true;
-    }
+// One output page, decided by the walk before a single byte is written (the host twin of
+// k_vc_walk / k_vc_encode, csrc/rj_varchar_dev.hip): a normal page holds result rows
+// [first, first + nr); piece k of a long string holds up to PAGE_BYTES - 4 of its characters.
+struct OutPage {
+    uint64_t first = 0;
+    uint32_t nr = 0;
+    uint32_t piece = 0;  // 0 = normal page, 1 + k = piece k of row `first`
 };
 
-struct PageWriter {
-    std::vector<uint8_t>& out;
-    uint64_t&             n_pages;
-    uint16_t              num_rows = 0;
-    std::vector<uint16_t> offs;
-    std::vector<char>     chars;
-    std::vector<uint8_t>  bitmap;
+// The fill rule of the reference's encoders (Table::to_columnar, src/build_table.cpp:595-677;
+// ColumnInserter<std::string>, include/plan.h:301-334) as arithmetic over three counters — rows,
+// non-NULL values and characters of the page being filled: a row goes to the next page when
+//     4 + 2 * values + chars + (rows / 8 + 1) > PAGE_BYTES
+// would hold with it in; a string longer than PAGE_BYTES - 7 closes the page and takes pages of
+// its own.
+void walk_pages(const std::vector<StrRef>& refs, std::vector<OutPage>& pages) {
+    uint64_t first = 0;
+    uint32_t rows = 0, vals = 0, chars = 0;
+    auto     close = [&](uint64_t next_first) {
+        if (rows) pages.push_back(OutPage{first, rows, 0});
+        first = next_first;
+        rows = vals = chars = 0;
+    };
+    for (uint64_t r = 0; r < refs.size(); ++r) {
+        const StrRef& s = refs[r];
+        if (s.len != NULL_LEN && s.len > PAGE_BYTES - 7) {
+            close(r + 1);
+            for (uint32_t off = 0, k = 0; off < s.len; off += PAGE_BYTES - 4, ++k)
+                pages.push_back(OutPage{r, 0, 1 + k});
+            continue;
+        }
+        const uint32_t add_v = s.len == NULL_LEN ? 0u : 1u, add_c = s.len == NULL_LEN ? 0u : s.len;
+        if (4 + 2 * (vals + add_v) + (chars + add_c) + (rows / 8 + 1) > PAGE_BYTES) close(r);
+        ++rows;
+        vals += add_v;
+        chars += add_c;
+    }
+    close(refs.size());
+}
 
-    uint8_t* new_page() {
-        out.resize(out.size() + PAGE_BYTES, 0);
-        ++n_pages;
-        return out.data() + out.size() - PAGE_BYTES;
-    }
-    void bit(uint16_t idx, bool set) {
-        while (bitmap.size() < (size_t)idx / 8 + 1) bitmap.push_back(0);
-        if (set) bitmap[idx / 8] |= (uint8_t)(1u << (idx % 8));
-    }
-    void save_page() {
-        uint8_t* page = new_page();
-        uint16_t nv = (uint16_t)offs.size();
-        memcpy(page, &num_rows, 2);
-        memcpy(page + 2, &nv, 2);
-        if (nv) memcpy(page + 4, offs.data(), (size_t)nv * 2);
-        if (!chars.empty()) memcpy(page + 4 + (size_t)nv * 2, chars.data(), chars.size());
-        memcpy(page + PAGE_BYTES - bitmap.size(), bitmap.data(), bitmap.size());
-        num_rows = 0;
-        offs.clear();
-        chars.clear();
-        bitmap.clear();
-    }
-    void save_long(const char* s, size_t len) {
-        size_t off = 0;
-        bool   first = true;
-        while (off < len) {
-            uint8_t* page = new_page();
-            uint16_t tag = first ? 0xffff : 0xfffe;
-            first = false;
-            size_t   chunk = std::min<size_t>(len - off, PAGE_BYTES - 4);
-            uint16_t n16 = (uint16_t)chunk;
-            memcpy(page, &tag, 2);
-            memcpy(page + 2, &n16, 2);
-            memcpy(page + 4, s + off, chunk);
-            off += chunk;
+// characters [off, off + n) of the long string whose chain starts at source page `pg`
+void copy_chain(const uint8_t* const* pages, uint64_t n_pages, uint64_t pg, uint32_t off, uint32_t n, uint8_t* dst) {
+    uint32_t at = 0;
+    for (uint64_t q = pg; q < n_pages && n; ++q) {
+        if (q != pg && rd16(pages[q]) != 0xfffe) break;
+        const uint32_t have = rd16(pages[q] + 2);
+        if (off < at + have) {
+            const uint32_t b = off - at, take = std::min(n, have - b);
+            memcpy(dst, pages[q] + 4 + b, take);
+            dst += take;
+            off += take;
+            n -= take;
         }
+        at += have;
     }
-    void add_null() {
-        if (4 + offs.size() * 2 + chars.size() + (num_rows / 8 + 1) > PAGE_BYTES) save_page();
-        bit(num_rows, false);
-        ++num_rows;
+}
+
+void write_page(const uint8_t* const* src_pages, uint64_t n_src, const std::vector<StrRef>& refs, const OutPage& op,
+                uint8_t* page) {
+    memset(page, 0, PAGE_BYTES);
+    if (op.piece) {  // piece of a long string: tag, character count, characters
+        const StrRef&  s = refs[op.first];
+        const uint32_t off = (op.piece - 1) * (PAGE_BYTES - 4);
+        const uint16_t tag = op.piece == 1 ? 0xffff : 0xfffe, n16 = (uint16_t)std::min<uint32_t>(s.len - off, PAGE_BYTES - 4);
+        memcpy(page, &tag, 2);
+        memcpy(page + 2, &n16, 2);
+        copy_chain(src_pages, n_src, s.chain - 1, off, n16, page + 4);
+        return;
     }
-    void add(const char* p, uint32_t len) {
-        if (len > PAGE_BYTES - 7) {
-            if (num_rows > 0) save_page();
-            save_long(p, len);
-            return;
-        }
-        if (4 + (offs.size() + 1) * 2 + (chars.size() + len) + (num_rows / 8 + 1) > PAGE_BYTES)
-            save_page();
-        bit(num_rows, true);
-        chars.insert(chars.end(), p, p + len);
-        offs.push_back((uint16_t)chars.size());
-        ++num_rows;
+    uint16_t nv = 0;
+    for (uint32_t i = 0; i < op.nr; ++i) nv += refs[op.first + i].len != NULL_LEN;
+    const uint16_t nr16 = (uint16_t)op.nr;
+    memcpy(page, &nr16, 2);
+    memcpy(page + 2, &nv, 2);
+    uint8_t* offs = page + 4;
+    uint8_t* text = page + 4 + (size_t)nv * 2;
+    uint8_t* bitmap = page + PAGE_BYTES - (op.nr + 7) / 8;
+    uint16_t end = 0, v = 0;
+    for (uint32_t i = 0; i < op.nr; ++i) {
+        const StrRef& s = refs[op.first + i];
+        if (s.len == NULL_LEN) continue;
+        bitmap[i >> 3] |= (uint8_t)(1u << (i & 7));
+        if (s.len) memcpy(text + end, s.p, s.len);
+        end = (uint16_t)(end + s.len);
+        memcpy(offs + (size_t)v * 2, &end, 2);
+        ++v;
     }
-    void finish() {
-        if (num_rows) save_page();
-    }
-};
+}
 }  // namespace
 
 void varchar_gather_encode(const uint8_t* const* pages, uint64_t n_pages,
                            const std::vector<uint64_t>& row_base, const uint32_t* idx, uint64_t n,
                            std::vector<uint8_t>& out_pages, uint64_t& n_out_pages) {
-    // Slabs of 64 K rows are encoded independently (each starts a fresh page — a valid,
-    // marginally less dense layout than one greedy pass) so large outputs use all host cores.
-    const uint64_t SLAB = 1u << 16;
-    uint64_t       n_slabs = (n + SLAB - 1) / SLAB;
     out_pages.clear();
     n_out_pages = 0;
-    // The lookups are a chain of dependent cache misses into random pages (header -> bitmap
-    // -> offset array -> characters).  Rows are resolved in batches, one link of the chain at
-    // a time with the next link prefetched, so the misses of a batch overlap.
-    auto encode = [&](uint64_t b, uint64_t e, std::vector<uint8_t>& out, uint64_t& np) {
-        Lookup     lk{pages, n_pages, row_base, {}};
-        PageWriter w{out, np};
-        out.reserve((e - b) * 24 + PAGE_BYTES);
+    // ---- 1. where does every result row's string sit?  The lookups are a chain of dependent
+    // cache misses into random pages (header -> bitmap -> offset array); rows are resolved in
+    // batches, one link of the chain at a time with the next link prefetched, so the misses of
+    // a batch overlap.  Parallel over the rows.
+    std::vector<StrRef> refs(n);
+    const uint64_t      covered = row_base[n_pages];
+    parallel_for(n, 1u << 14, [&](size_t b, size_t e) {
         constexpr int  B = 32;
         const uint8_t* page[B];
         const uint8_t* bitmap[B];
-        const char*    str[B];
-        uint32_t       at[B], len[B];
-        int            kind[B];  // 0 = NULL, 1 = string in str/len, 2 = long string (slow path)
-        const uint64_t covered = row_base[n_pages];
+        uint64_t       pgi[B];
+        uint32_t       at[B];
+        int            kind[B];  // 0 = NULL, 1 = short string, 2 = long string
         for (uint64_t base = b; base < e; base += B) {
             const int m = (int)std::min<uint64_t>(B, e - base);
             for (int k = 0; k < m; ++k) {
-                uint64_t row = idx[base + k];
+                const uint64_t row = idx[base + k];
                 page[k] = nullptr;
                 if (row >= covered) continue;  // rows the pages do not cover are NULL
-                uint64_t pg = (uint64_t)(std::upper_bound(row_base.begin(), row_base.end(), row) -
-                                         row_base.begin()) - 1;
-                page[k] = pages[pg];
-                at[k] = (uint32_t)(row - row_base[pg]);
+                pgi[k] = (uint64_t)(std::upper_bound(row_base.begin(), row_base.end(), row) - row_base.begin()) - 1;
+                page[k] = pages[pgi[k]];
+                at[k] = (uint32_t)(row - row_base[pgi[k]]);
                 __builtin_prefetch(page[k]);
             }
             for (int k = 0; k < m; ++k) {
                 kind[k] = 0;
                 if (!page[k]) continue;
-                uint16_t nr = rd16(page[k]);
+                const uint16_t nr = rd16(page[k]);
                 if (nr == 0xffff) {
                     kind[k] = 2;
                     continue;
@@ -240,52 +230,46 @@ void varchar_gather_encode(const uint8_t* const* pages, uint64_t n_pages,
                 __builtin_prefetch(page[k] + 4 + (size_t)at[k] * 2);
             }
             for (int k = 0; k < m; ++k) {
-                if (kind[k] != 1) continue;
-                const uint8_t* offs = page[k] + 4;
-                uint16_t       nnn = rd16(page[k] + 2);
-                uint32_t       end = rd16(offs + (size_t)at[k] * 2);
-                uint32_t       beg = at[k] ? rd16(offs + (size_t)(at[k] - 1) * 2) : 0;
-                str[k] = reinterpret_cast<const char*>(page[k]) + 4 + (size_t)nnn * 2 + beg;
-                len[k] = end - beg;
-                __builtin_prefetch(str[k]);
-                __builtin_prefetch(str[k] + len[k]);
-            }
-            for (int k = 0; k < m; ++k) {
-                if (kind[k] == 1) {
-                    w.add(str[k], len[k]);
-                } else if (kind[k] == 2) {
-                    const char* p;
-                    uint32_t    l;
-                    if (lk.get(idx[base + k], &p, &l))
-                        w.add(p, l);
-                    else
-                        w.add_null();
-                } else {
-                    w.add_null();
+                StrRef& r = refs[base + k];
+                if (kind[k] == 0) {
+                    r.len = NULL_LEN;
+                } else if (kind[k] == 1) {
+                    const uint8_t* offs = page[k] + 4;
+                    const uint16_t nnn = rd16(page[k] + 2);
+                    const uint32_t end = rd16(offs + (size_t)at[k] * 2);
+                    const uint32_t beg = at[k] ? rd16(offs + (size_t)(at[k] - 1) * 2) : 0;
+                    r.p = reinterpret_cast<const char*>(page[k]) + 4 + (size_t)nnn * 2 + beg;
+                    r.len = end - beg;
+                    __builtin_prefetch(r.p);
+                } else {  // a long string: its length is the sum over its page chain
+                    uint32_t len = rd16(page[k] + 2);
+                    for (uint64_t q = pgi[k] + 1; q < n_pages && rd16(pages[q]) == 0xfffe; ++q) len += rd16(pages[q] + 2);
+                    r.len = len;
+                    r.chain = (uint32_t)pgi[k] + 1;
+                    if (len <= PAGE_BYTES - 7) {
+                        // (a chain the reference's encoders would never have produced: short enough
+                        // for a normal page.  Materialise it so that it can be copied like one.)
+                        char* tmp = new char[len ? len : 1];
+                        copy_chain(pages, n_pages, pgi[k], 0, len, reinterpret_cast<uint8_t*>(tmp));
+                        r.p = tmp;
+                    }
                 }
             }
         }
-        w.finish();
-    };
-    if (n_slabs <= 1) {
-        encode(0, n, out_pages, n_out_pages);
-        return;
-    }
-    std::vector<std::vector<uint8_t>> parts(n_slabs);
-    std::vector<uint64_t>             counts(n_slabs, 0);
-    parallel_for(n_slabs, 1, [&](size_t b, size_t e) {
-        for (size_t s = b; s < e; ++s)
-            encode(s * SLAB, std::min<uint64_t>(n, (s + 1) * SLAB), parts[s], counts[s]);
     });
-    size_t total = 0;
-    for (auto& p : parts) total += p.size();
-    out_pages.resize(total);
-    size_t off = 0;
-    for (uint64_t s = 0; s < n_slabs; ++s) {
-        memcpy(out_pages.data() + off, parts[s].data(), parts[s].size());
-        off += parts[s].size();
-        n_out_pages += counts[s];
-    }
+    // ---- 2. page boundaries: the sequential fill rule, counters only
+    std::vector<OutPage> plan;
+    plan.reserve(n / 64 + 16);
+    walk_pages(refs, plan);
+    // ---- 3. every page is written straight into its final place, pages in parallel
+    n_out_pages = plan.size();
+    out_pages.resize(plan.size() * (size_t)PAGE_BYTES);
+    uint8_t* out = out_pages.data();
+    parallel_for(plan.size(), 16, [&](size_t b, size_t e) {
+        for (size_t p = b; p < e; ++p) write_page(pages, n_pages, refs, plan[p], out + p * PAGE_BYTES);
+    });
+    for (StrRef& r : refs)
+        if (r.chain && r.len <= PAGE_BYTES - 7) delete[] r.p;
 }
 
 }  // namespace rj

@@ -381,6 +381,13 @@ void launch_vc_compact(const Launch& L, const uint8_t* keep, const uint32_t* bid
     RJ_VLAUNCH(L, "varchar_compact", k_vc_compact, (n + 255) / 256, 256, keep, bidx, pidx, n, out_b, out_p, cursor);
 }
 
+// RJ_CTX_PREWARM: one harmless launch, so that HIP loads this translation unit's code object when
+// the context is built (zeroed[0..64) must be zero: a `keep` mask of zeros compacts nothing)
+void prewarm_varchar_dev(const Launch& L, uint32_t* zeroed) {
+    RJ_VLAUNCH(L, "prewarm", k_vc_compact, 1, 256, reinterpret_cast<const uint8_t*>(zeroed), zeroed, zeroed, 1u, zeroed,
+               zeroed, reinterpret_cast<unsigned long long*>(zeroed));
+}
+
 void launch_vc_walk(const Launch& L, const VcRow* rows, uint32_t n, uint32_t* pages_in_chunk,
                     const uint32_t* page_base, VcPage* page_out) {
     if (!n) return;

@@ -37,6 +37,7 @@ void* build_context() {
     rj_config            cfg{};
     std::vector<int32_t> devs;
     cfg.device = -1;
+    cfg.flags = RJ_CTX_PREWARM;  // set-up cost lands here, not in the first query's execute()
     if (const char* e = std::getenv("RJ_DEVICES")) {
         std::string v(e);
         if (v == "all") {

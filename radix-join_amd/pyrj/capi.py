@@ -37,11 +37,12 @@ class rj_config(C.Structure):
         ("rank_base", C.c_int32),
         ("comm_id", C.POINTER(rj_comm_id)),
         ("exchange", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("flags", C.c_int32),
     ]
 
 
 EXCHANGE_AUTO, EXCHANGE_P2P, EXCHANGE_RCCL = 0, 1, 2
+CTX_PREWARM = 1
 
 
 class rj_tuples(C.Structure):
@@ -94,6 +95,7 @@ EXPORTS = [
     "rj_result_copy_pages",
     "rj_result_device_pages",
     "rj_result_free",
+    "rj_exchange_plan",
     "rj_shard_partition",
     "rj_join_tuples",
     "rj_profile_read",
@@ -294,7 +296,7 @@ class Context:
     """rj_context*: ``Contest::build_context()`` / ``destroy_context()``."""
 
     def __init__(self, device=-1, profile=False, stream=None, radix_bits=0, devices=None, world_size=0,
-                 rank_base=0, comm_id=None, exchange=EXCHANGE_AUTO, _lane_of=None, _handle=None):
+                 rank_base=0, comm_id=None, exchange=EXCHANGE_AUTO, prewarm=False, _lane_of=None, _handle=None):
         """devices: HIP ordinals this context owns (one rank each; an ordinal may repeat =
         virtual ranks on one GPU); world_size/rank_base/comm_id: this process' place in a
         multi-process job (comm_id = bytes from ``make_comm_id()`` of one process)."""
@@ -310,6 +312,7 @@ class Context:
             self._devs = (C.c_int32 * len(devices))(*devices)
             cfg.n_devices, cfg.devices = len(devices), self._devs
         cfg.world_size, cfg.rank_base, cfg.exchange = world_size, rank_base, exchange
+        cfg.flags = CTX_PREWARM if prewarm else 0  # what Contest::build_context() sets
         if comm_id is not None or exchange == EXCHANGE_RCCL:
             preload_torch_rccl()
         if comm_id is not None:
@@ -459,6 +462,31 @@ def plan_shardable(plan: pl.Plan):
     ok = L.rj_plan_shardable(C.byref(cplan), buf, 256)
     del keep
     return bool(ok), buf.value.decode()
+
+
+def exchange_plan(world: int, subs: int, rank: int, counts) -> dict:
+    """rj_exchange_plan: rank `rank`'s half of the exchange step of a sharded join, from the
+    all-gathered count tensor counts[src, dst, sub] (tuples).  Host arithmetic only: needs no GPU."""
+    L = load()
+    cnt = np.ascontiguousarray(np.asarray(counts, dtype=np.uint64).reshape(world, world, subs))
+    u64 = lambda n: np.zeros(n, dtype=np.uint64)  # noqa: E731
+    u32 = lambda n: np.zeros(n, dtype=np.uint32)  # noqa: E731
+    out = {
+        "send_off": u64(world), "send_cnt": u64(world), "recv_off": u64(world), "recv_cnt": u64(world),
+        "seg_begin": u32(subs * world), "seg_end": u32(subs * world), "part_off": u32(subs + 1),
+    }
+    n_recv = C.c_uint64(0)
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    L.rj_exchange_plan.restype = C.c_int
+    L.rj_exchange_plan.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32] + [C.c_void_p] * 8 + [C.POINTER(C.c_uint64)]
+    rc = L.rj_exchange_plan(world, subs, rank, ptr(cnt), ptr(out["send_off"]), ptr(out["send_cnt"]), ptr(out["recv_off"]),
+                            ptr(out["recv_cnt"]), ptr(out["seg_begin"]), ptr(out["seg_end"]), ptr(out["part_off"]),
+                            C.byref(n_recv))
+    if rc != 0:
+        L.rj_last_error.restype = C.c_char_p
+        raise RjError(rc, (L.rj_last_error(None) or b"").decode())
+    out["n_recv"] = int(n_recv.value)
+    return out
 
 
 def make_comm_id() -> bytes:

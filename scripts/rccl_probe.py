@@ -29,7 +29,21 @@ if what in ("rj", "both"):
     with open("/proc/self/maps") as f:
         libs = sorted({ln.split()[-1] for ln in f if "rccl" in ln or "amdhip64" in ln})
     print("loaded:", libs, flush=True)
-    ctx = capi.Context(devices=[0], world_size=1, rank_base=0, comm_id=cid, exchange=capi.EXCHANGE_RCCL)
-    print("rj context with RCCL communicator ok", flush=True)
+    import time
+
+    t0 = time.time()
+    try:
+        ctx = capi.Context(devices=[0], world_size=1, rank_base=0, comm_id=cid, exchange=capi.EXCHANGE_RCCL)
+    except capi.RjError as e:
+        # (bring-up is bounded by RJ_EXCHANGE_TIMEOUT_MS; a helper thread may still sit inside RCCL)
+        print(f"rj context FAILED after {time.time() - t0:.1f} s: {e}", flush=True)
+        with open("/proc/self/maps") as f:
+            libs = sorted({ln.split()[-1] for ln in f if "rccl" in ln or "amdhip64" in ln})
+        print("loaded at failure:", libs, flush=True)
+        os._exit(3)
+    print(f"rj context with RCCL communicator ok after {time.time() - t0:.1f} s", flush=True)
+    with open("/proc/self/maps") as f:
+        libs = sorted({ln.split()[-1] for ln in f if "rccl" in ln or "amdhip64" in ln})
+    print("loaded:", libs, flush=True)
     ctx.destroy()
     print("destroyed", flush=True)

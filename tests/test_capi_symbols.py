@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(lib):
     for name in _declared():
         assert hasattr(lib, name), f"librj.so does not export {name}"
     lib.rj_abi_version.restype = ctypes.c_int
-    assert lib.rj_abi_version() == 2
+    assert lib.rj_abi_version() == 3
 
 
 def test_no_gpu_fails_loudly_without_fallback(lib):
@@ -66,8 +66,9 @@ def test_product_never_touches_the_oracle():
 
 
 def test_plan_shardable_is_decided_from_the_plan_alone():
-    """rj_plan_shardable needs neither a context nor a GPU: every JoinNode may carry at most one
-    fixed-width non-key column per side, and no scan may output VARCHAR"""
+    """rj_plan_shardable needs neither a context nor a GPU: per side of a JoinNode, what must travel
+    with the key has to fit the carry words (3 words behind an INT32 key, 2 behind a 64-bit one; at
+    most one 64-bit column), and no scan may output VARCHAR"""
     from pyrj import capi
     from pyrj import plan as pl
 
@@ -83,7 +84,13 @@ def test_plan_shardable_is_decided_from_the_plan_alone():
     ok, why = capi.plan_shardable(plan([(0, i32), (1, i64)], [(0, i32), (1, i32)], [(0, i32), (1, i64), (3, i32)]))
     assert ok and why == ""
     ok, why = capi.plan_shardable(plan([(0, i32), (1, i64), (2, i32)], [(0, i32)], [(1, i64), (2, i32)]))
-    assert not ok and "more than one non-key column" in why
+    assert ok and why == ""  # INT64 + INT32 = three carry words
+    ok, why = capi.plan_shardable(plan([(0, i32), (1, i32), (2, i32), (3, i32)], [(0, i32)], [(1, i32), (2, i32), (3, i32)]))
+    assert ok
+    ok, why = capi.plan_shardable(plan([(0, i32), (1, i64), (2, i64)], [(0, i32)], [(1, i64), (2, i64)]))
+    assert not ok and "more payload than travels with the key" in why
+    ok, why = capi.plan_shardable(plan([(0, i64), (1, i64), (2, i32)], [(0, i64)], [(1, i64), (2, i32)]))
+    assert not ok  # a 64-bit key leaves two carry words
     ok, why = capi.plan_shardable(plan([(0, i32), (1, vc)], [(0, i32)], [(1, vc)]))
     assert not ok and "VARCHAR" in why
     # two joins, each within the limit

@@ -174,6 +174,29 @@ def test_random_plan_forced_radix_xcd_placement(seed, bits):
     assert pl.canonical_rows(got) == pl.canonical_rows(want)
 
 
+# Payload columns travel with the key when they fit the carry words (CARRY_WIDE, the default since
+# round 3); with RJ_TUNE_WIDE_CARRY=0 a row index travels instead and every column is gathered
+# afterwards (k_gather) — that path stays covered by the same plans.
+@pytest.mark.parametrize("bits", [0, 11])
+@pytest.mark.parametrize("seed", range(_FIRST, _FIRST + min(_COUNT, 60)))
+def test_random_plan_row_index_carries(seed, bits):
+    p = random_plan(seed)
+    want = _oracle.execute(p)
+    if want.num_rows > 400_000:
+        pytest.skip("result too large to sort in a unit test")
+    os.environ["RJ_TUNE_WIDE_CARRY"] = "0"  # read once, when the context is created
+    try:
+        c = capi.Context(radix_bits=bits)
+    finally:
+        del os.environ["RJ_TUNE_WIDE_CARRY"]
+    try:
+        got = capi.execute(p, c)
+    finally:
+        c.destroy()
+    assert got.num_rows == want.num_rows
+    assert pl.canonical_rows(got) == pl.canonical_rows(want)
+
+
 # VARCHAR join keys (reference hash_join_omp<std::string>) in the mix: the same generator with
 # VARCHAR as the plan's key type most of the time; own seed range so that the plans above stay
 # what they were.  Also under a forced multi-pass radix plan (the 64-bit string hashes then go

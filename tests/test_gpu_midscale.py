@@ -27,6 +27,9 @@ _KNOBS = {
     "default": ({}, {}),
     "xcd": ({"RJ_TUNE_XCD_MIN_ROWS": "0"}, {}),
     "side": ({"RJ_TUNE_XCD_MIN_ROWS": "0", "RJ_TUNE_AOS_MID": "1", "RJ_TUNE_PACKED_SIDE": "1"}, {"radix_bits": 16}),
+    # 12-byte tuples between the passes WITHOUT the side array: the later histogram reads the keys
+    # out of the tuples (Aos3KeyLoader)
+    "mid3": ({"RJ_TUNE_XCD_MIN_ROWS": "0", "RJ_TUNE_AOS_MID": "3"}, {"radix_bits": 16}),
 }
 
 

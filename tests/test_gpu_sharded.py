@@ -191,18 +191,52 @@ def test_empty_sides_and_empty_shards():
 def test_unshardable_plans_are_refused_loudly():
     rng = np.random.default_rng(26)
     n = 10_000
-    bt = pl.make_table([(pl.INT32, rng.permutation(n).astype(np.int32)), (pl.INT32, np.arange(n, dtype=np.int32)), (pl.INT64, np.arange(n, dtype=np.int64))])
     pt = pl.make_table([(pl.INT32, rng.integers(0, n, n).astype(np.int32)), (pl.INT32, np.arange(n, dtype=np.int32))])
     p = pl.Plan()
-    p.new_scan_node(0, [(0, pl.INT32), (1, pl.INT32), (2, pl.INT64)])
+    bt = pl.make_table([(pl.INT32, rng.permutation(n).astype(np.int32)), (pl.INT64, np.arange(n, dtype=np.int64)), (pl.INT64, np.arange(n, dtype=np.int64))])
+    p.new_scan_node(0, [(0, pl.INT32), (1, pl.INT64), (2, pl.INT64)])
     p.new_scan_node(1, [(0, pl.INT32), (1, pl.INT32)])
-    p.new_join_node(True, 0, 1, 0, 0, [(0, pl.INT32), (1, pl.INT32), (2, pl.INT64), (4, pl.INT32)])  # two payload columns of one side
+    p.new_join_node(True, 0, 1, 0, 0, [(0, pl.INT32), (1, pl.INT64), (2, pl.INT64), (4, pl.INT32)])  # two INT64 payloads of one side: 4 carry words
     p.new_input(bt)
     p.new_input(pt)
     p.root = 2
+    assert not capi.plan_shardable(p)[0]
     with pytest.raises(capi.RjError) as e:
         run_sharded(p, 2)
     assert e.value.code == 5 and "row index" in e.value.message
+
+
+@pytest.mark.parametrize("n_ranks", [2, 8])
+def test_wide_carries_shard(n_ranks):
+    """Several payload columns per side and NULL-bearing ones travel with the key (up to three carry
+    words, validity bits in a word of their own), so such joins shard: INT32 + INT64 on the build
+    side, two INT32 (one with NULLs) on the probe side, NULL keys, duplicates — and a second join
+    on top whose build side is that (distributed) result."""
+    rng = np.random.default_rng(60 + n_ranks)
+    nb, npr = 500_000, 1_100_000
+    bt = pl.make_table([
+        (pl.INT32, rng.integers(0, 400_000, nb).astype(np.int32), rng.random(nb) > 0.02),
+        (pl.INT32, rng.integers(-(2**31), 2**31 - 1, nb).astype(np.int32)),
+        (pl.INT64, rng.integers(-(2**62), 2**62, nb).astype(np.int64)),
+    ])
+    pt = pl.make_table([
+        (pl.INT32, rng.integers(0, 420_000, npr).astype(np.int32)),
+        (pl.INT32, rng.integers(0, 1000, npr).astype(np.int32), rng.random(npr) > 0.3),
+        (pl.INT32, np.arange(npr, dtype=np.int32)),
+    ])
+    tt = pl.make_table([(pl.INT32, rng.integers(0, 1000, 3000).astype(np.int32)), (pl.FP64, rng.standard_normal(3000))])
+    p = pl.Plan()
+    a = p.new_scan_node(0, [(0, pl.INT32), (1, pl.INT32), (2, pl.INT64)])
+    b = p.new_scan_node(1, [(0, pl.INT32), (1, pl.INT32), (2, pl.INT32)])
+    j1 = p.new_join_node(True, a, b, 0, 0, [(2, pl.INT64), (4, pl.INT32), (1, pl.INT32), (5, pl.INT32), (0, pl.INT32)])
+    c = p.new_scan_node(2, [(0, pl.INT32), (1, pl.FP64)])
+    # probe side of the second join = the first join's result, keyed by its NULL-bearing column
+    j2 = p.new_join_node(False, j1, c, 1, 0, [(0, pl.INT64), (6, pl.FP64), (3, pl.INT32), (1, pl.INT32)])
+    for x in (bt, pt, tt):
+        p.new_input(x)
+    p.root = j2
+    assert capi.plan_shardable(p)[0]
+    check_against_oracle(p, n_ranks)
 
 
 def test_rccl_transport_at_world_size_one():
@@ -219,6 +253,92 @@ def test_rccl_transport_at_world_size_one():
     print(r.stdout, r.stderr[-2000:])
     assert r.returncode == 0, r.stdout + r.stderr[-2000:]
     assert "rccl world-1 join matches the oracle" in r.stdout
+
+
+def _child(args, timeout=300):
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "_rccl_fail.py")] + args, capture_output=True, text=True, timeout=timeout)
+    print(r.stdout, r.stderr[-2000:])
+    assert r.returncode == 0, r.stdout + r.stderr[-2000:]
+    return r.stdout
+
+
+@pytest.mark.parametrize("at", [1, 2, 3])
+def test_rccl_local_failure_is_agreed_on_before_the_exchange(at):
+    """A rank that fails locally (while preparing, in stage A, or allocating its receive buffers)
+    reports it in the status word of the next count all-gather; every rank gives up before the
+    all-to-all — an error within seconds instead of peers blocked in a collective."""
+    out = _child(["inject", str(at)])
+    assert "surfaced after" in out and "joins correctly afterwards" in out
+
+
+def test_rccl_bring_up_without_its_peers_is_bounded():
+    """Rank 0 of a two-rank job whose rank 1 never starts: ncclCommInitRank would wait forever;
+    the bring-up runs on a helper thread against RJ_EXCHANGE_TIMEOUT_MS and fails loudly."""
+    out = _child(["bringup"], timeout=120)
+    assert "bring-up without its peer failed after" in out
+
+
+@pytest.mark.parametrize("at", [1, 2, 3])
+def test_virtual_ranks_local_failure_of_one_rank(at):
+    """The same agreement among four virtual ranks of one process: rank 2 fails, the call returns
+    its error, nothing hangs, and the context joins correctly afterwards."""
+    import os
+
+    rng = np.random.default_rng(40 + at)
+    nb, npr = 300_000, 500_000
+    bt = pl.make_table([(pl.INT32, rng.permutation(nb).astype(np.int32)), (pl.INT64, rng.integers(0, 2**40, nb).astype(np.int64))])
+    pt = pl.make_table([(pl.INT32, rng.integers(0, nb, npr).astype(np.int32)), (pl.INT32, np.arange(npr, dtype=np.int32))])
+    plan = join_plan(bt, pt, [pl.INT32, pl.INT64], [pl.INT32, pl.INT32], [(0, pl.INT32), (1, pl.INT64), (3, pl.INT32)])
+    os.environ["RJ_DEBUG_SHARD_FAIL"] = str(at)
+    os.environ["RJ_DEBUG_SHARD_FAIL_RANK"] = "2"
+    try:
+        with pytest.raises(capi.RjError) as e:
+            run_sharded(plan, 4)
+        assert e.value.code == 3 and "injected failure" in e.value.message and "rank 2" in e.value.message
+    finally:
+        del os.environ["RJ_DEBUG_SHARD_FAIL"], os.environ["RJ_DEBUG_SHARD_FAIL_RANK"]
+    check_against_oracle(plan, 4)
+
+
+def test_rccl_refuses_virtual_ranks_and_owner_digit_can_stay_unfolded():
+    """RCCL cannot run two ranks on one device: refused up front (RJ_ERR_ARG), not tried.  And the
+    join is the same with stage A partitioning by owner rank only (RJ_TUNE_FOLD_OWNER=0)."""
+    import os
+
+    with pytest.raises(capi.RjError) as e:
+        capi.Context(devices=[0, 0], exchange=capi.EXCHANGE_RCCL, comm_id=b"\0" * 128)
+    assert e.value.code == 1 and "appears twice" in e.value.message
+    rng = np.random.default_rng(41)
+    nb, npr = 700_000, 900_000
+    bt = pl.make_table([(pl.INT32, rng.permutation(nb).astype(np.int32)), (pl.INT32, np.arange(nb, dtype=np.int32))])
+    pt = pl.make_table([(pl.INT32, rng.integers(0, nb, npr).astype(np.int32)), (pl.INT64, rng.integers(0, 2**40, npr).astype(np.int64))])
+    plan = join_plan(bt, pt, [pl.INT32, pl.INT32], [pl.INT32, pl.INT64], [(0, pl.INT32), (1, pl.INT32), (3, pl.INT64)])
+    os.environ["RJ_TUNE_FOLD_OWNER"] = "0"
+    try:
+        check_against_oracle(plan, 4)
+    finally:
+        del os.environ["RJ_TUNE_FOLD_OWNER"]
+    check_against_oracle(plan, 4, radix_bits=13)  # folded: 4 owners x 2^7 digits in stage A, 2^6 behind the exchange
+    # a per-device handle of lanes 1.. is owned by its group: destroying it is a documented no-op
+    ctx = capi.Context(devices=[0, 0])
+    try:
+        ctx.L.rj_context_destroy(ctx.lane(1).h)
+        assert b"per-device handle" in ctx.L.rj_last_error(ctx.lane(1).h)
+        tables = [[ctx.lane(d).upload(t) for t in shard] for d, shard in enumerate(zip(*[shard_table(t, 2) for t in plan.inputs]))]
+        res = ctx.execute_sharded(plan, tables)
+        assert sum(r.num_rows for r in res) == _oracle.execute(plan).num_rows
+        for r in res:
+            r.free()
+        for row in tables:
+            for t in row:
+                t.release()
+    finally:
+        ctx.destroy()
 
 
 def test_plain_context_runs_execute_sharded_as_one_rank():
@@ -244,7 +364,7 @@ def test_contest_execute_semantics_over_several_devices():
     of INT32 and INT64 columns alike), the plan runs sharded, the result is the concatenation of
     the ranks' pages.  A plan that cannot be sharded runs on the first device instead."""
     rng = np.random.default_rng(29)
-    nb, npr = 4_500_000, 6_100_000
+    nb, npr = 4_500_000, 8_200_000  # (>= 4 cut units of 1984 * 1007 rows: four ranks all get a shard)
     bt = pl.make_table([(pl.INT32, rng.permutation(nb).astype(np.int32)), (pl.INT64, rng.integers(-(2**62), 2**62, nb).astype(np.int64))])
     pt = pl.make_table([(pl.INT32, rng.integers(0, nb + 50_000, npr).astype(np.int32)), (pl.INT32, np.arange(npr, dtype=np.int32))])
     plan = join_plan(bt, pt, [pl.INT32, pl.INT64], [pl.INT32, pl.INT32], [(0, pl.INT32), (1, pl.INT64), (3, pl.INT32)])
