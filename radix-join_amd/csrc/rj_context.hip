@@ -218,6 +218,12 @@ void Context::prewarm() {
     parallel_for(4096, 1, [](size_t, size_t) {});  // spins up the host pool
     BufP         b = buf(256);
     const Launch L = launch();
+    // first use of the copy engines in both directions, on both streams
+    memset(pinned_up, 0, 256);
+    RJ_HIP(hipMemcpyAsync(b->p, pinned_up, 256, hipMemcpyHostToDevice, copy_stream));
+    RJ_HIP(hipStreamSynchronize(copy_stream));
+    RJ_HIP(hipMemcpyAsync(pinned, b->p, 256, hipMemcpyDeviceToHost, stream));
+    RJ_HIP(hipMemcpyAsync(pinned_small, b->p, 64, hipMemcpyDeviceToHost, stream));
     RJ_HIP(hipMemsetAsync(b->p, 0, 256, stream));
     launch_scan_bins(L, b->as<uint32_t>(), 1, b->as<uint32_t>() + 8, nullptr);  // rj_kernels.hip's code object
     prewarm_varchar_dev(L, b->as<uint32_t>());                                    // rj_varchar_dev.hip's

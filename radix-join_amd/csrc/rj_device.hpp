@@ -132,6 +132,10 @@ struct PassParams {
     // digit from the LOW ones, one pass for both): hi_shift != 0 =>
     //   digit = ((w >> shift) & ((1 << lo_bits) - 1)) | ((w >> hi_shift) << lo_bits)
     uint32_t        hi_shift, lo_bits;
+    // phase cycle counters of the scatter kernels (a diagnostic build, -DRJ_PT_DIAG=1, with
+    // RJ_DIAG=3 at run time): thread 0 of every workgroup adds the cycles between consecutive
+    // stamps to diag[phase]; nullptr otherwise
+    unsigned long long* diag;
 };
 
 // digit of hashed key word `w` in this pass (mask = fan-out - 1)

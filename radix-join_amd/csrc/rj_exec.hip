@@ -528,6 +528,29 @@ class Exec {
                                          n_oseg, F, pp.xcd_log2, off->as<uint32_t>(), pp.cursor);
                 }
                 if (p == 0 && after_offsets) (*after_offsets)(off->as<uint32_t>());
+                BufP pt_diag;
+                if (ctx->tune.diag >= 3) {  // phase stamps of the scatter (diagnostic build only)
+                    pt_diag = ctx->buf(8 * 8);
+                    RJ_HIP(hipMemsetAsync(pt_diag->p, 0, 64, ctx->stream));
+                    pp.diag = pt_diag->as<unsigned long long>();
+                }
+                struct DiagDump {
+                    Context* ctx; BufP b; uint32_t p; uint64_t n; bool aos;
+                    ~DiagDump() {
+                        if (!b) return;
+                        unsigned long long h[8];
+                        if (hipMemcpyAsync(h, b->p, 64, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return;
+                        (void)hipStreamSynchronize(ctx->stream);
+                        static const char* names[] = {"clear+tail", "load issue+hash", "rank+barrier", "reserve+scan",
+                                                      "stage A", "copy-out A", "stage B", "copy-out B"};
+                        double tot = 0;
+                        for (int i = 0; i < 8; ++i) tot += (double)h[i];
+                        if (tot <= 0) return;
+                        fprintf(stderr, "[rj diag] scatter pass %u over %llu tuples, phase shares (thread 0 cycles):", p, (unsigned long long)n);
+                        for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * h[i] / tot);
+                        fprintf(stderr, "  (%.0f cycles per tile)\n", tot / ((double)n / PT_TILE));
+                    }
+                } diag_dump{ctx, pt_diag, p, n, false};
                 if (aos_mid) {
                     const bool last = p + 1 == passes;
                     Words      o{};

@@ -658,16 +658,27 @@ struct SrcLoader {
     // not parking it in the L2 (pass-1 histogram 1.47 -> 1.38 ms at 1 B rows, the fine histogram
     // 0.115 -> 0.085 ms at 100 M); the scatter kernels lose with the same hint (their loads
     // compete with half-written output lines for the L2: profiles/r02_ax_*), so they do not use it
+    // Addresses are formed as a UNIFORM 64-bit tile base (the page that holds the tile's first row,
+    // or the first row itself for dense columns) plus a 32-bit per-lane byte offset — one VGPR per
+    // outstanding load instead of a 64-bit pair, and no 64-bit vector arithmetic: with all loads of
+    // a tile in flight at once the 64-bit form spilled to scratch.
     template <bool NT = false>
     __device__ __forceinline__ static void load_col32(const ColRef& c, bool vec, uint32_t base,
                                                       uint32_t end, uint32_t (&out)[PT_ITEMS]) {
         const bool     paged = c.kind == COL_PAGED;
-        const uint8_t* p = c.ptr;
+        const uint32_t ub = __builtin_amdgcn_readfirstlane(base);
+        const uint32_t p0 = ub / ROWS32, s0 = ub - p0 * ROWS32;  // page / slot of the tile's first row
+        const uint8_t* tp = paged ? c.ptr + (size_t)p0 * PAGE_BYTES : c.ptr + (size_t)ub * 4u;
+        // byte offset of row base + rel from tp, branch-free for both kinds:
+        //   dense  rel * 4
+        //   paged  q * PAGE + HDR + (t - q * ROWS) * 4  =  rel * 4 + (s0 * 4 + HDR) + q * (PAGE - ROWS * 4),
+        //          t = s0 + rel, q = t / ROWS  (pages crossed since the tile's first page)
+        const uint32_t bias = paged ? s0 * 4u + HDR32 : 0u, per_page = paged ? PAGE_BYTES - ROWS32 * 4u : 0u;
+        auto           off = [&](uint32_t rel) -> uint32_t { return rel * 4u + bias + ((s0 + rel) / ROWS32) * per_page; };
         if (vec) {
 #pragma unroll
             for (int v = 0; v < PT_ITEMS / 4; ++v) {
-                const uint32_t r0 = base + (v * PT_THREADS + threadIdx.x) * 4;
-                const u32x4a* q = reinterpret_cast<const u32x4a*>(p + col_off32(paged, r0));
+                const u32x4a* q = reinterpret_cast<const u32x4a*>(tp + off((v * PT_THREADS + threadIdx.x) * 4u));
                 u32x4a        x;
                 if constexpr (NT)
                     x = __builtin_nontemporal_load(q);
@@ -677,11 +688,34 @@ struct SrcLoader {
                 for (int e = 0; e < 4; ++e) out[4 * v + e] = x[e];
             }
         } else {
+            const uint32_t last = end - 1u - ub;
 #pragma unroll
-            for (int j = 0; j < PT_ITEMS; ++j) {
-                const uint32_t ic = min(base + j * PT_THREADS + threadIdx.x, end - 1u);
-                out[j] = *reinterpret_cast<const uint32_t*>(p + col_off32(paged, ic));
-            }
+            for (int j = 0; j < PT_ITEMS; ++j)
+                out[j] = *reinterpret_cast<const uint32_t*>(tp + off(min((uint32_t)(j * PT_THREADS + threadIdx.x), last)));
+        }
+    }
+    template <bool NT = false>
+    __device__ __forceinline__ static void load_col64(const ColRef& c, bool vec, uint32_t base,
+                                                      uint32_t end, uint32_t (&lo)[PT_ITEMS],
+                                                      uint32_t (&hi)[PT_ITEMS]) {
+        const bool     paged = c.kind == COL_PAGED;
+        const uint32_t ub = __builtin_amdgcn_readfirstlane(base);
+        const uint32_t p0 = ub / ROWS64, s0 = ub - p0 * ROWS64;
+        const uint8_t* tp = paged ? c.ptr + (size_t)p0 * PAGE_BYTES : c.ptr + (size_t)ub * 8u;
+        const uint32_t last = end - 1u - ub;
+        const uint32_t bias = paged ? s0 * 8u + HDR64 : 0u, per_page = paged ? PAGE_BYTES - ROWS64 * 8u : 0u;
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS; ++j) {
+            const uint32_t rel = min(item_row(vec, 0u, j), last);
+            const uint32_t o = rel * 8u + bias + ((s0 + rel) / ROWS64) * per_page;  // (see load_col32)
+            const uint64_t* a = reinterpret_cast<const uint64_t*>(tp + o);
+            uint64_t        v;
+            if constexpr (NT)
+                v = __builtin_nontemporal_load(a);
+            else
+                v = *a;
+            lo[j] = (uint32_t)v;
+            hi[j] = (uint32_t)(v >> 32);
         }
     }
     // a 32-bit column of any kind (a base table's row-id column included)
@@ -692,25 +726,6 @@ struct SrcLoader {
             for (int j = 0; j < PT_ITEMS; ++j) out[j] = item_row(vec, base, j);
         } else {
             load_col32(c, vec, base, end, out);
-        }
-    }
-    template <bool NT = false>
-    __device__ __forceinline__ static void load_col64(const ColRef& c, bool vec, uint32_t base,
-                                                      uint32_t end, uint32_t (&lo)[PT_ITEMS],
-                                                      uint32_t (&hi)[PT_ITEMS]) {
-        const bool     paged = c.kind == COL_PAGED;
-        const uint8_t* p = c.ptr;
-#pragma unroll
-        for (int j = 0; j < PT_ITEMS; ++j) {
-            const uint32_t ic = min(item_row(vec, base, j), end - 1u);
-            const uint64_t* q = reinterpret_cast<const uint64_t*>(p + col_off64(paged, ic));
-            uint64_t        v;
-            if constexpr (NT)
-                v = __builtin_nontemporal_load(q);
-            else
-                v = *q;
-            lo[j] = (uint32_t)v;
-            hi[j] = (uint32_t)(v >> 32);
         }
     }
 
@@ -1059,6 +1074,24 @@ __global__ __launch_bounds__(PT_MAXF) void k_scan_fine(const uint32_t* fine, uin
 // bytes instead of 128 + 256 in two places), and the join reads one stream.  The tile is staged
 // in two halves by sorted position (8192 tuples = 96 KiB of LDS each), so the runs are still
 // those of the whole 16384-tuple tile.
+#ifndef RJ_PT_DIAG
+#define RJ_PT_DIAG 0
+#endif
+#if RJ_PT_DIAG
+#define RJ_PT_STAMP(PHASE)                                                      \
+    do {                                                                        \
+        if (pp.diag) {                                                          \
+            unsigned long long _t = __builtin_amdgcn_s_memtime();               \
+            if (threadIdx.x == 0) atomicAdd(&pp.diag[PHASE], _t - diag_t);      \
+            diag_t = _t;                                                        \
+        }                                                                       \
+    } while (0)
+#else
+#define RJ_PT_STAMP(PHASE) \
+    do {                   \
+    } while (0)
+#endif
+
 template <int NW, class Loader, int PAIR, bool AOS>
 __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassParams pp, Words out) {
     static_assert(PAIR < 0 || (PAIR >= 1 && PAIR + 1 < NW), "pair = two carry words behind the key");
@@ -1076,15 +1109,20 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassPara
     // Thread d owns digit d's write cursor in a REGISTER: the reservation's round trip is
     // not waited for until the first tile has been loaded and ranked.
     uint32_t run = 0;  // thread d: where digit d's run of the current tile starts in the output
+#if RJ_PT_DIAG
+    unsigned long long diag_t = pp.diag ? __builtin_amdgcn_s_memtime() : 0ull;
+#endif
 
     for (uint32_t base = begin; base < end; base += PT_TILE) {
         for (uint32_t d = threadIdx.x; d < F; d += PT_THREADS) s_cnt[d] = 0;
         lds_barrier();
+        RJ_PT_STAMP(0);  // counters cleared (+ the previous tile's tail)
 
         uint32_t w[PT_ITEMS][NW];
         uint32_t dr[PT_ITEMS];  // digit << 16 | rank, 0xffffffff = no tuple
         // every load of the tile is issued before the first rank is taken
         const uint32_t ok = ld.template load_tile<NW>(base, end, w);
+        RJ_PT_STAMP(1);  // loads issued (+ hashing, which waits for the key loads)
 #pragma unroll
         for (int j = 0; j < PT_ITEMS; ++j) {
             dr[j] = 0xffffffffu;
@@ -1095,6 +1133,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassPara
             }
         }
         lds_barrier();
+        RJ_PT_STAMP(2);  // ranked (LDS atomics) + barrier
 
         // PT_THREADS >= PT_MAXF: thread d scans digit d
         // Thread d reserves digit d's range of this tile with one global atomic; its round
@@ -1107,13 +1146,18 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassPara
         uint32_t ex = block_excl_scan(c, s_wsum, total);
         if (threadIdx.x < F) s_base[threadIdx.x] = ex;
         lds_barrier();
+        RJ_PT_STAMP(3);  // reservation issued + digit scan
 
         // LDS position of every tuple, computed once for all word arrays
 #pragma unroll
         for (int j = 0; j < PT_ITEMS; ++j)
             if (dr[j] != 0xffffffffu) dr[j] = s_base[dr[j] >> 16] + (dr[j] & 0xffffu);
 
-        if constexpr (AOS) {
+        // key + two-word carry (NW == 3): keys and carry pairs of half the sorted tile are staged
+        // TOGETHER and copied out together — as 12-byte tuples (AOS) or into the key array and the
+        // pair array — so no per-element destination has to be kept in registers between the two
+        // arrays (the 16 extra VGPRs spilled to scratch)
+        if constexpr (NW == 3 && PAIR == 1) {
             constexpr uint32_t HALF = PT_TILE / 2;
             uint2* const       s_p = s_stage2;                                      // [HALF] carries
             uint32_t* const    s_k = reinterpret_cast<uint32_t*>(s_stage2 + HALF);  // [HALF] keys
@@ -1129,6 +1173,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassPara
                     }
                 }
                 lds_barrier();
+                RJ_PT_STAMP(4);  // (AOS) half staged (waits for the carry loads)
 #pragma unroll
                 for (int k = 0; k < PT_ITEMS / 2; ++k) {
                     const uint32_t i = k * PT_THREADS + threadIdx.x, gi = h * HALF + i;
@@ -1136,14 +1181,20 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassPara
                         const uint32_t v = s_k[i];
                         const uint2    c = s_p[i];
                         const uint32_t g = s_delta[pass_digit(pp, v, mask)] + gi;
-                        uint32_t*      o = out.w[0] + (size_t)g * 3u;
-                        o[0] = v;
-                        o[1] = c.x;
-                        o[2] = c.y;
-                        if (pp.side_out) pp.side_out[g] = (uint16_t)((v >> pp.next_shift) & pp.next_mask);
+                        if constexpr (AOS) {
+                            uint32_t* o = out.w[0] + (size_t)g * 3u;
+                            o[0] = v;
+                            o[1] = c.x;
+                            o[2] = c.y;
+                            if (pp.side_out) pp.side_out[g] = (uint16_t)((v >> pp.next_shift) & pp.next_mask);
+                        } else {
+                            out.w[0][g] = v;
+                            reinterpret_cast<uint2*>(out.w[1])[g] = c;
+                        }
                     }
                 }
                 lds_barrier();
+                RJ_PT_STAMP(5);  // (AOS) half copied out (stores issued)
             }
             continue;
         }
@@ -1155,6 +1206,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassPara
             if (dr[j] != 0xffffffffu) s_stage[dr[j]] = w[j][0];
         if (threadIdx.x < F) s_delta[threadIdx.x] = run - ex;  // global index = delta + LDS position
         lds_barrier();
+        RJ_PT_STAMP(4);  // word 0 staged
         uint32_t dest[PT_ITEMS];
 #pragma unroll
         for (int k = 0; k < PT_ITEMS; ++k) {
@@ -1167,6 +1219,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassPara
             }
         }
         lds_barrier();
+        RJ_PT_STAMP(5);  // word 0 copied out (stores issued)
 #pragma unroll
         for (int a = 1; a < NW; ++a) {
             if constexpr (PAIR >= 0) {
@@ -1177,6 +1230,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassPara
                         if (dr[j] != 0xffffffffu)
                             s_stage2[dr[j]] = make_uint2(w[j][a], w[j][a + 1 < NW ? a + 1 : a]);
                     lds_barrier();
+                    RJ_PT_STAMP(6);  // carry pair staged (waits for the carry loads)
                     uint2* dst2 = reinterpret_cast<uint2*>(out.w[a]);
 #pragma unroll
                     for (int k = 0; k < PT_ITEMS; ++k) {
@@ -1184,6 +1238,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassPara
                         if (i < total) dst2[dest[k]] = s_stage2[i];
                     }
                     lds_barrier();
+                    RJ_PT_STAMP(7);  // carry pair copied out (stores issued)
                     continue;
                 }
             }

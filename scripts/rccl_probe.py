@@ -9,6 +9,8 @@ faulthandler.enable()
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "radix-join_amd")]
 what = sys.argv[1] if len(sys.argv) > 1 else "both"
+# "truncated": as "rj", but the communicator id is cut at its first NUL byte and zero-padded — what
+# reading a ctypes c_char array as `.bytes` / `.value` does to an ncclUniqueId
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", "29533")
@@ -21,11 +23,14 @@ if what in ("torch", "both"):
     dist.all_reduce(t)
     torch.cuda.synchronize()
     print("torch nccl all_reduce ok", t.tolist(), flush=True)
-if what in ("rj", "both"):
+if what in ("rj", "both", "truncated"):
     from pyrj import capi
 
     cid = capi.make_comm_id()
-    print("comm id ok", len(cid), flush=True)
+    print("comm id ok", len(cid), "first NUL at byte", cid.find(b"\0"), flush=True)
+    if what == "truncated":
+        cut = cid.find(b"\0")
+        cid = cid[:cut] + b"\0" * (128 - cut)
     with open("/proc/self/maps") as f:
         libs = sorted({ln.split()[-1] for ln in f if "rccl" in ln or "amdhip64" in ln})
     print("loaded:", libs, flush=True)
