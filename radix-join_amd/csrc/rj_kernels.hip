@@ -345,10 +345,24 @@ __global__ __launch_bounds__(PT_MAXF) void k_scan_segments(const uint32_t* hist,
 // the compiler can issue the whole tile's loads back to back behind a single wait.  The
 // returned bit mask says which items hold a tuple.
 // PAIR >= 0: in.w[PAIR] is an array of 8-byte {word PAIR, word PAIR+1} pairs (a two-word carry)
+// (issue_tile / finish_tile: the two halves of load_tile for the scatter's software pipeline —
+// issue only ISSUES the tile's loads, finish does what needs the data.  Loaders of tuples that are
+// already in the partition layout have nothing to finish.)
+#define RJ_TRIVIAL_ISSUE_FINISH                                                                              \
+    template <int NW>                                                                                        \
+    __device__ __forceinline__ uint32_t issue_tile(uint32_t base, uint32_t end, uint32_t (&w)[PT_ITEMS][NW]) const { \
+        return this->template load_tile<NW>(base, end, w);                                                   \
+    }                                                                                                        \
+    template <int NW>                                                                                        \
+    __device__ __forceinline__ uint32_t finish_tile(uint32_t, uint32_t, uint32_t ok, uint32_t (&)[PT_ITEMS][NW]) const { \
+        return ok;                                                                                           \
+    }
+
 template <int PAIR>
 struct DenseLoaderT {
     static constexpr int pair = PAIR;
     Words in;
+    RJ_TRIVIAL_ISSUE_FINISH
     // two-halves interface of the fine histogram (see SrcLoader): the words are hashed already
     __device__ __forceinline__ uint32_t issue_keys(uint32_t base, uint32_t end, uint32_t (&lo)[PT_ITEMS],
                                                    uint32_t (&)[PT_ITEMS]) const {
@@ -434,10 +448,12 @@ struct DenseLoaderT {
 
 using DenseLoader = DenseLoaderT<-1>;
 
+
 // One array of 12-byte {hashed key, carry lo, carry hi} tuples (what every pass of a key +
 // two-word-carry plan writes): four consecutive tuples = three 16-byte loads.
 struct Aos3Loader {
     const uint32_t* in;
+    RJ_TRIVIAL_ISSUE_FINISH
     template <int NW>
     __device__ __forceinline__ uint32_t load_tile(uint32_t base, uint32_t end, uint32_t (&w)[PT_ITEMS][NW]) const {
         static_assert(NW == 3, "12-byte tuples");
@@ -562,8 +578,8 @@ struct DigitLoader {
 // Partitioned tuples of ONE key word + ONE carry word can also be kept packed: an array of
 // 8-byte {hashed key, carry} pairs instead of two word arrays (see k_pass_scatter_packed).
 struct PackedLoader {
-    static constexpr bool kPrefetch = true;  // load_tile has no post-processing: safe to issue early
     const uint2* in;
+    RJ_TRIVIAL_ISSUE_FINISH
     __device__ __forceinline__ uint32_t issue_keys(uint32_t base, uint32_t end, uint32_t (&lo)[PT_ITEMS],
                                                    uint32_t (&)[PT_ITEMS]) const {
         return key_tile(base, end, lo);
@@ -641,7 +657,6 @@ __device__ __forceinline__ uint64_t col_off64(bool paged, uint32_t row) {
 // has NULLs, is one of the 32-bit columns by then: k_pack_validity).
 template <int KW, int CW, int WIDE = WIDE_NONE>
 struct SrcLoader {
-    static constexpr bool kPrefetch = false;
     static_assert(WIDE == WIDE_NONE || (WIDE == WIDE_32S && CW >= 2) || (WIDE == WIDE_64_32 && CW == 3), "wide carry layouts");
     TupleSrc s;
 
@@ -802,9 +817,12 @@ struct SrcLoader {
         ok = drop_invalid(base + PT_TILE <= end, base, end, ok);
         return hash_keys(ok, lo, hi);
     }
+    // The tile in two halves (see issue_keys / finish_keys): issue_tile ISSUES every load of the
+    // tile — raw key words into w[.][0..KW), carry words behind them — and finish_tile, which
+    // needs the key data, drops invalid rows and hashes the keys in place.
     template <int NW>
-    __device__ __forceinline__ uint32_t load_tile(uint32_t base, uint32_t end,
-                                                  uint32_t (&w)[PT_ITEMS][NW]) const {
+    __device__ __forceinline__ uint32_t issue_tile(uint32_t base, uint32_t end,
+                                                   uint32_t (&w)[PT_ITEMS][NW]) const {
         static_assert(NW == KW + CW, "word count");
         const bool vec = base + PT_TILE <= end;
         uint32_t   lo[PT_ITEMS], hi[PT_ITEMS];
@@ -852,6 +870,23 @@ struct SrcLoader {
                 }
             }
         }
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS; ++j) {
+            w[j][0] = lo[j];
+            if constexpr (KW == 2) w[j][1] = hi[j];
+        }
+        return ok;
+    }
+    template <int NW>
+    __device__ __forceinline__ uint32_t finish_tile(uint32_t base, uint32_t end, uint32_t ok,
+                                                    uint32_t (&w)[PT_ITEMS][NW]) const {
+        const bool vec = base + PT_TILE <= end;
+        uint32_t   lo[PT_ITEMS], hi[PT_ITEMS];
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS; ++j) {
+            lo[j] = w[j][0];
+            hi[j] = KW == 2 ? w[j][KW - 1] : 0u;
+        }
         ok = drop_invalid(vec, base, end, ok);
         ok = hash_keys(ok, lo, hi);
 #pragma unroll
@@ -860,6 +895,11 @@ struct SrcLoader {
             if constexpr (KW == 2) w[j][1] = hi[j];
         }
         return ok;
+    }
+    template <int NW>
+    __device__ __forceinline__ uint32_t load_tile(uint32_t base, uint32_t end,
+                                                  uint32_t (&w)[PT_ITEMS][NW]) const {
+        return finish_tile<NW>(base, end, issue_tile<NW>(base, end, w), w);
     }
 };
 
@@ -1077,6 +1117,14 @@ __global__ __launch_bounds__(PT_MAXF) void k_scan_fine(const uint32_t* fine, uin
 #ifndef RJ_PT_DIAG
 #define RJ_PT_DIAG 0
 #endif
+// Tile prefetch in the key + two-word-carry scatter (next tile's loads issued behind the second
+// half's staging): measured SLOWER at 1 B rows — pass 1 10.4-11.3 -> 12.0 ms, pass 2 9.5 -> 10.2 ms per
+// step (profiles/r03_h_scatter_tile_prefetch_ab.log): the kernels are bound by the memory system's
+// mix of reads and partial-line writes, not by a CU's load latency, and a burst of loads next to
+// the copy-out's stores only gets in their way.  Off; -DRJ_PT_PIPELINE=1 builds it for A/B.
+#ifndef RJ_PT_PIPELINE
+#define RJ_PT_PIPELINE 0
+#endif
 #if RJ_PT_DIAG
 #define RJ_PT_STAMP(PHASE)                                                      \
     do {                                                                        \
@@ -1113,15 +1161,25 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassPara
     unsigned long long diag_t = pp.diag ? __builtin_amdgcn_s_memtime() : 0ull;
 #endif
 
+    // (RJ_PT_PIPELINE, off — see above: the tile's registers are dead once its second half has been
+    // staged, so the NEXT tile's loads could be issued there and fly during that half's copy-out)
+    constexpr bool PIPE = NW == 3 && PAIR == 1 && RJ_PT_PIPELINE;
+    uint32_t       w[PT_ITEMS][NW];
+    uint32_t       ok_raw = 0;
+    if constexpr (PIPE) ok_raw = ld.template issue_tile<NW>(begin, end, w);
+
     for (uint32_t base = begin; base < end; base += PT_TILE) {
         for (uint32_t d = threadIdx.x; d < F; d += PT_THREADS) s_cnt[d] = 0;
         lds_barrier();
         RJ_PT_STAMP(0);  // counters cleared (+ the previous tile's tail)
 
-        uint32_t w[PT_ITEMS][NW];
         uint32_t dr[PT_ITEMS];  // digit << 16 | rank, 0xffffffff = no tuple
         // every load of the tile is issued before the first rank is taken
-        const uint32_t ok = ld.template load_tile<NW>(base, end, w);
+        uint32_t ok;
+        if constexpr (PIPE)
+            ok = ld.template finish_tile<NW>(base, end, ok_raw, w);
+        else
+            ok = ld.template load_tile<NW>(base, end, w);
         RJ_PT_STAMP(1);  // loads issued (+ hashing, which waits for the key loads)
 #pragma unroll
         for (int j = 0; j < PT_ITEMS; ++j) {
@@ -1174,6 +1232,9 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassPara
                 }
                 lds_barrier();
                 RJ_PT_STAMP(4);  // (AOS) half staged (waits for the carry loads)
+                if constexpr (PIPE) {
+                    if (h == 1 && base + PT_TILE < end) ok_raw = ld.template issue_tile<NW>(base + PT_TILE, end, w);
+                }
 #pragma unroll
                 for (int k = 0; k < PT_ITEMS / 2; ++k) {
                     const uint32_t i = k * PT_THREADS + threadIdx.x, gi = h * HALF + i;
@@ -1275,17 +1336,16 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter_packed(Loader ld, P
     const uint32_t F = 1u << pp.fanout_log2, mask = F - 1u;
 
     uint32_t run = 0;  // thread d: where digit d's run of the current tile starts in the output
-    // kPrefetch loaders: the next tile's loads are issued as soon as this tile has been staged
-    // (its registers are dead then) and fly during the copy-out
+    // the next tile's loads are issued as soon as this tile has been staged (its registers are
+    // dead then) and fly during the copy-out
     uint32_t w[PT_ITEMS][2];
-    uint32_t ok = 0;
-    if constexpr (Loader::kPrefetch) ok = ld.template load_tile<2>(begin, end, w);
+    uint32_t ok_raw = ld.template issue_tile<2>(begin, end, w);
     for (uint32_t base = begin; base < end; base += PT_TILE) {
         for (uint32_t d = threadIdx.x; d < F; d += PT_THREADS) s_cnt[d] = 0;
         lds_barrier();
 
-        uint32_t dr[PT_ITEMS];  // digit << 16 | rank, 0xffffffff = no tuple
-        if constexpr (!Loader::kPrefetch) ok = ld.template load_tile<2>(base, end, w);
+        uint32_t       dr[PT_ITEMS];  // digit << 16 | rank, 0xffffffff = no tuple
+        const uint32_t ok = ld.template finish_tile<2>(base, end, ok_raw, w);  // (source tuples: NULL drop + hashing)
 #pragma unroll
         for (int j = 0; j < PT_ITEMS; ++j) {
             dr[j] = 0xffffffffu;
@@ -1310,9 +1370,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter_packed(Loader ld, P
         for (int j = 0; j < PT_ITEMS; ++j)
             if (dr[j] != 0xffffffffu)
                 s_stage[s_base[dr[j] >> 16] + (dr[j] & 0xffffu)] = make_uint2(w[j][0], w[j][1]);
-        if constexpr (Loader::kPrefetch) {
-            if (base + PT_TILE < end) ok = ld.template load_tile<2>(base + PT_TILE, end, w);
-        }
+        if (base + PT_TILE < end) ok_raw = ld.template issue_tile<2>(base + PT_TILE, end, w);
         if (threadIdx.x < F) s_delta[threadIdx.x] = run - ex;  // global index = delta + LDS position
         lds_barrier();
 
