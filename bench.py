@@ -55,7 +55,7 @@ from pyrj import workloads as wl  # noqa: E402
 adopt, join_plan, pack_pages_gpu, pack_pages_gpu64, zipf_keys = wl.adopt, wl.join_plan, wl.pack_pages_gpu, wl.pack_pages_gpu64, wl.zipf_keys
 
 HBM_PEAK_GBPS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic_r02.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic_r03.json")
 
 
 def algo_bytes(payload_bytes):

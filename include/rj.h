@@ -166,6 +166,52 @@ int  rj_table_adopt_device(rj_context* ctx, uint64_t num_rows, uint64_t n_cols,
                            const uint64_t* n_pages, rj_table** out);
 void rj_table_release(rj_context* ctx, rj_table* t);
 
+/* ---------------------------------------------------------------- ingest --
+ * rj_table_from_csv ↔ Table::from_csv(attributes, path, filter) (reference include/table.h:19-22,
+ * src/build_table.cpp:135-304) with the CSV text already in host memory and the dialect the
+ * harness uses (escape '\\', separator ',', no header, no trailing comma: :231; parser
+ * src/csv_parser.cpp:3-175): the text is parsed ON THE DEVICE (quote-aware record / field
+ * boundaries, typed fields, empty field = NULL as in TableParser::on_field :31-35), the filter is
+ * evaluated on the device, and the rows that pass are packed into Page images in HBM with the
+ * page-fill rule of ColumnInserter (reference include/plan.h:151-335) — the resident table a
+ * ScanNode then reads without any upload.  Runs BEFORE execute() in the harness and is untimed
+ * there (tests/read_sql.cpp:1100-1107,1232-1236): SURVEY.md §8(f)#4.
+ * Column types: INT32, INT64, VARCHAR (FP64 text is not parsed on the device:
+ * RJ_ERR_UNSUPPORTED).  At most 2^32 - 16 bytes of text.
+ * Errors (RJ_ERR_DATA) as the reference raises them: "CSV parse error" (a record with another
+ * number of fields than n_cols, a quote left open: csv_parser.h:9-14, build_table.cpp:236,243),
+ * "parse integer error" (:42-44).
+ *
+ * filter: a postfix program over the table's columns (reference include/statement.h,
+ * src/statement.cpp:46-135,186-201) — comparison and IS [NOT] NULL leaves push a row bitmap,
+ * RJ_F_AND / RJ_F_OR pop two, RJ_F_NOT pops one; n_filter_ops == 0 keeps every row.  NULL
+ * semantics are the reference's bitmap arithmetic: a comparison is false on NULL, NOT flips every
+ * bit (so NOT (x < 5) holds for NULL x).  Predicates the device does not evaluate — LIKE /
+ * NOT LIKE (RE2 in the reference, statement.h:118-161) and the other string comparisons — come in
+ * as RJ_F_HOST_BITMAP leaves: bit r (LSB first) of host_bitmap = row r of the CSV passes.       */
+typedef enum rj_filter_opcode {
+    RJ_F_EQ = 0, RJ_F_NEQ = 1, RJ_F_LT = 2, RJ_F_GT = 3, RJ_F_LEQ = 4, RJ_F_GEQ = 5, /* column <op> ivalue (INT32 / INT64 columns;
+                                        an INT32 column compares with (int32_t)ivalue: statement.cpp:55)        */
+    RJ_F_IS_NULL = 6, RJ_F_IS_NOT_NULL = 7,                   /* any column                                   */
+    RJ_F_HOST_BITMAP = 8,
+    RJ_F_AND = 9, RJ_F_OR = 10, RJ_F_NOT = 11
+} rj_filter_opcode;
+
+typedef struct rj_filter_op {
+    int32_t        op;          /* rj_filter_opcode */
+    int32_t        column;      /* leaves */
+    int64_t        ivalue;      /* comparison leaves */
+    const uint8_t* host_bitmap; /* RJ_F_HOST_BITMAP: (rows + 7) / 8 bytes, rows = records of the CSV */
+} rj_filter_op;
+
+int rj_table_from_csv(rj_context* ctx, const char* text, uint64_t n_bytes, uint64_t n_cols,
+                      const int32_t* col_type, const rj_filter_op* filter, uint64_t n_filter_ops,
+                      rj_table** out);
+/* A resident table's shape and pages (tests compare them with the reference's fill rule). */
+uint64_t rj_table_num_rows(const rj_table* t);
+uint64_t rj_table_col_pages(const rj_table* t, uint64_t col);
+int      rj_table_copy_pages(rj_context* ctx, const rj_table* t, uint64_t col, void* const* dst, uint64_t n_dst);
+
 /* --------------------------------------------------------------- execute --
  * rj_execute ↔ Contest::execute(const Plan&, void*) (src/execute.cpp:316-324):
  *   inputs are the host pages in plan->inputs; the result pages are produced

@@ -17,7 +17,7 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/fetch" -- python3 "$root/bench.py" $args > "$out/fetch.log" 2>&1
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/write" -- python3 "$root/bench.py" $args > "$out/write.log" 2>&1
 cd "$root"
-[ -f gpurun_out/traffic.json ] || cp profiles/traffic_r02.json gpurun_out/traffic.json
+[ -f gpurun_out/traffic.json ] || cp profiles/traffic_r03.json gpurun_out/traffic.json 2>/dev/null || cp profiles/traffic_r02.json gpurun_out/traffic.json
 python3 scripts/prof_summary.py "$out" "gpurun_out/$tag.md" gpurun_out/traffic.json "$wlname" \
     "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py $args"
 cp "$(find "$out/trace" -name '*kernel_stats.csv' | head -1)" "gpurun_out/${tag}_kernel_stats.csv"
