@@ -163,6 +163,27 @@ int rj_table_adopt_device(rj_context* ctx, uint64_t num_rows, uint64_t n_cols,
     });
 }
 
+int rj_table_from_csv(rj_context* ctx, const char* text, uint64_t n_bytes, uint64_t n_cols, const int32_t* col_type,
+                      const rj_filter_op* filter, uint64_t n_filter_ops, rj_table** out) {
+    if (!ctx || !out || (n_filter_ops && !filter)) return RJ_ERR_ARG;
+    *out = nullptr;
+    return guarded(ctx, [&] {
+        RJ_HIP(hipSetDevice(ctx->device));
+        *out = static_cast<rj_table*>(table_from_csv(ctx, text, n_bytes, n_cols, col_type, filter, n_filter_ops));
+    });
+}
+
+uint64_t rj_table_num_rows(const rj_table* t) { return t ? t->num_rows : 0; }
+uint64_t rj_table_col_pages(const rj_table* t, uint64_t col) { return table_col_pages(t, col); }
+
+int rj_table_copy_pages(rj_context* ctx, const rj_table* t, uint64_t col, void* const* dst, uint64_t n_dst) {
+    if (!ctx || !t || (n_dst && !dst)) return RJ_ERR_ARG;
+    return guarded(ctx, [&] {
+        RJ_HIP(hipSetDevice(ctx->device));
+        table_copy_pages(ctx, t, col, dst, n_dst);
+    });
+}
+
 void rj_table_release(rj_context* ctx, rj_table* t) {
     (void)ctx;
     delete t;

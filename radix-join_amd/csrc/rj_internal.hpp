@@ -305,6 +305,12 @@ void   upload_host_pages(Context* ctx, const uint8_t* const* pages, uint64_t n_p
 Result* execute_host_sharded(Context* group, const rj_plan* plan, const std::vector<bool>& used,
                              const std::vector<std::vector<bool>>& col_used);
 
+// rj_ingest.hip — Table::from_csv on the device
+Table*   table_from_csv(Context* ctx, const char* text, uint64_t n_bytes, uint64_t n_cols, const int32_t* col_type,
+                        const rj_filter_op* filter, uint64_t n_filter_ops);
+uint64_t table_col_pages(const Table* t, uint64_t col);
+void     table_copy_pages(Context* ctx, const Table* t, uint64_t col, void* const* dst, uint64_t n_dst);
+
 // rj_hostpool.cpp (host only)
 // fn(b, e) over disjoint ranges of at most `grain` items covering [0, n), on the process-wide
 // worker threads plus the caller; the first exception thrown by fn is rethrown here.

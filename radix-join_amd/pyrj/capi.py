@@ -55,6 +55,34 @@ class rj_tuples(C.Structure):
     ]
 
 
+class rj_filter_op(C.Structure):
+    _fields_ = [("op", C.c_int32), ("column", C.c_int32), ("ivalue", C.c_int64), ("host_bitmap", C.c_void_p)]
+
+
+# rj_filter_opcode (include/rj.h): a filter is a postfix program, e.g.
+#   [("LT", 2, 1990), ("IS_NULL", 4), ("NOT",), ("AND",), ("BITMAP", np.packbits(mask, bitorder="little")), ("OR",)]
+F_OPS = {"EQ": 0, "NEQ": 1, "LT": 2, "GT": 3, "LEQ": 4, "GEQ": 5, "IS_NULL": 6, "IS_NOT_NULL": 7, "BITMAP": 8, "AND": 9, "OR": 10, "NOT": 11}
+
+
+def filter_to_c(prog):
+    """-> (rj_filter_op array, n, keep-alive list)"""
+    prog = list(prog or [])
+    arr = (rj_filter_op * max(1, len(prog)))()
+    keep = []
+    for k, term in enumerate(prog):
+        op = F_OPS[term[0]]
+        arr[k].op = op
+        if op <= 5:
+            arr[k].column, arr[k].ivalue = int(term[1]), int(term[2])
+        elif op in (6, 7):
+            arr[k].column = int(term[1])
+        elif op == 8:
+            bm = np.ascontiguousarray(term[1], dtype=np.uint8)
+            keep.append(bm)
+            arr[k].host_bitmap = bm.ctypes.data
+    return arr, len(prog), keep
+
+
 class rj_kernel_stat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
 
@@ -86,6 +114,10 @@ EXPORTS = [
     "rj_table_upload",
     "rj_table_adopt_device",
     "rj_table_release",
+    "rj_table_from_csv",
+    "rj_table_num_rows",
+    "rj_table_col_pages",
+    "rj_table_copy_pages",
     "rj_execute",
     "rj_execute_resident",
     "rj_result_num_rows",
@@ -374,6 +406,41 @@ class Context:
         h = C.c_void_p()
         self._check(self.L.rj_table_upload(self.h, C.byref(inp), C.byref(h)))
         return Table(self, h)
+
+    def from_csv(self, text: bytes, types, filt=None) -> Table:
+        """rj_table_from_csv: ``Table::from_csv`` on the device — CSV text (the harness's dialect) ->
+        a resident table of the rows that pass `filt` (a postfix program, see F_OPS)."""
+        n = len(types)
+        ct = (C.c_int32 * n)(*types)
+        ops, n_ops, keep = filter_to_c(filt)
+        h = C.c_void_p()
+        self.L.rj_table_from_csv.restype = C.c_int
+        self.L.rj_table_from_csv.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_int32), C.POINTER(rj_filter_op),
+                                             C.c_uint64, C.POINTER(C.c_void_p)]
+        self._check(self.L.rj_table_from_csv(self.h, text, len(text), n, ct, ops, n_ops, C.byref(h)))
+        del keep
+        t = Table(self, h)
+        t.types = list(types)
+        return t
+
+    def table_to_host(self, t: Table, types=None) -> pl.ColumnarTable:
+        """The pages of a resident table, copied out (rj_table_copy_pages)."""
+        types = types or t.types
+        L = self.L
+        L.rj_table_num_rows.restype = C.c_uint64
+        L.rj_table_num_rows.argtypes = [C.c_void_p]
+        L.rj_table_col_pages.restype = C.c_uint64
+        L.rj_table_col_pages.argtypes = [C.c_void_p, C.c_uint64]
+        L.rj_table_copy_pages.restype = C.c_int
+        L.rj_table_copy_pages.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.c_uint64]
+        cols = []
+        for c, ty in enumerate(types):
+            npg = int(L.rj_table_col_pages(t.h, c))
+            pages = np.zeros((npg, pg.PAGE_SIZE), dtype=np.uint8)
+            ptrs = (C.c_void_p * max(1, npg))(*[pages[i].ctypes.data for i in range(npg)])
+            self._check(L.rj_table_copy_pages(self.h, t.h, c, ptrs, npg))
+            cols.append(pl.Column(ty, pages))
+        return pl.ColumnarTable(int(L.rj_table_num_rows(t.h)), cols)
 
     def adopt_device(self, num_rows, types, dev_ptrs, n_pages, keep=None) -> Table:
         n = len(types)

@@ -1,0 +1,130 @@
+"""Random tables and their CSV text in the dialect the reference's harness reads (Table::from_csv,
+reference src/build_table.cpp:231: separator ',', escape '\\', quotes '"', no header): a small model
+used by the ingest tests — rows as Python values (None = NULL, int, bytes), a writer that quotes
+and escapes at random wherever the dialect allows it, and an independent row-level evaluator of the
+filter programs."""
+import numpy as np
+
+INT32, INT64, VARCHAR = 0, 1, 3
+_SPECIAL = b',"\n\r'
+
+
+def random_rows(rng, n, types, null_p=0.1, long_p=0.0):
+    cols = []
+    for ty in types:
+        nulls = rng.random(n) < null_p
+        if ty == INT32:
+            v = rng.integers(-(2**31), 2**31 - 1, n)
+            small = rng.random(n) < 0.5
+            v[small] = rng.integers(-50, 2050, int(small.sum()))
+            cols.append([None if nulls[i] else int(v[i]) for i in range(n)])
+        elif ty == INT64:
+            v = rng.integers(-(2**63), 2**63 - 1, n)
+            cols.append([None if nulls[i] else int(v[i]) for i in range(n)])
+        else:
+            alphabet = np.frombuffer(b"abcdefghij KLMNOP0123456789,\"\\\n\r;:'-_", dtype=np.uint8)
+            lens = rng.integers(1, 40, n)
+            lens[rng.random(n) < 0.02] = rng.integers(200, 1500, int((rng.random(n) < 0.02).sum()) or 1)[0]
+            col = []
+            for i in range(n):
+                if nulls[i]:
+                    col.append(None)
+                    continue
+                ln = int(lens[i])
+                if long_p and rng.random() < long_p:
+                    ln = int(rng.integers(8186, 30000))
+                col.append(alphabet[rng.integers(0, len(alphabet), ln)].tobytes())
+            cols.append(col)
+    return [tuple(c[i] for c in cols) for i in range(n)]
+
+
+def field_text(rng, v):
+    if v is None:
+        return b"" if rng.random() < 0.8 else b'""'  # an empty field is NULL, quoted or not
+    if isinstance(v, (int, np.integer)):
+        s = str(int(v)).encode()
+        return b'"' + s + b'"' if rng.random() < 0.1 else s
+    must = any(ch in _SPECIAL for ch in v)
+    if must or rng.random() < 0.3:
+        # inside quotes a backslash escapes '"' and itself; before any other character it stands
+        # for itself, so it MAY be left alone there — but not at the end (it would take the quote)
+        out = bytearray(b'"')
+        for k, ch in enumerate(v):
+            if ch == 0x22:
+                out += b'\\"'
+            elif ch == 0x5C:
+                nxt = v[k + 1] if k + 1 < len(v) else 0x22
+                out += b"\\\\" if nxt in (0x22, 0x5C) or rng.random() < 0.5 else b"\\"
+            else:
+                out.append(ch)
+        out += b'"'
+        return bytes(out)
+    return v
+
+
+def to_csv(rng, rows, crlf_p=0.2, final_newline=True):
+    out = bytearray()
+    for r, row in enumerate(rows):
+        out += b",".join(field_text(rng, v) for v in row)
+        last = r + 1 == len(rows)
+        if last and not final_newline:
+            break
+        x = rng.random()
+        out += b"\r\n" if x < crlf_p else (b"\r" if x < crlf_p * 1.2 else b"\n")
+    return bytes(out)
+
+
+def eval_filter(prog, row, r):
+    """row-level twin of the reference's bitmap arithmetic (statement.cpp:8-135,186-201)"""
+    if not prog:
+        return True
+    st = []
+    for term in prog:
+        op = term[0]
+        if op in ("AND", "OR"):
+            b, a = st.pop(), st.pop()
+            st.append((a and b) if op == "AND" else (a or b))
+        elif op == "NOT":
+            st.append(not st.pop())
+        elif op == "BITMAP":
+            st.append(bool((term[1][r >> 3] >> (r & 7)) & 1))
+        elif op == "IS_NULL":
+            st.append(row[term[1]] is None)
+        elif op == "IS_NOT_NULL":
+            st.append(row[term[1]] is not None)
+        else:
+            x, y = row[term[1]], term[2]
+            if x is None:
+                st.append(False)
+            else:
+                st.append({"EQ": x == y, "NEQ": x != y, "LT": x < y, "GT": x > y, "LEQ": x <= y, "GEQ": x >= y}[op])
+    assert len(st) == 1
+    return st[0]
+
+
+def random_filter(rng, rows, types, depth=3):
+    n = len(rows)
+    leaves = []
+    for c, ty in enumerate(types):
+        leaves.append(lambda c=c: ("IS_NULL", c))
+        leaves.append(lambda c=c: ("IS_NOT_NULL", c))
+        if ty == INT32:
+            leaves.append(lambda c=c: (["EQ", "NEQ", "LT", "GT", "LEQ", "GEQ"][int(rng.integers(0, 6))], c, int(rng.integers(-100, 2100))))
+        elif ty == INT64:
+            leaves.append(lambda c=c: (["LT", "GT", "LEQ", "GEQ"][int(rng.integers(0, 4))], c, int(rng.integers(-(2**62), 2**62))))
+        else:
+            # a predicate the host evaluates (LIKE '%a%'): handed over as a bitmap
+            def like(c=c):
+                mask = np.array([row[c] is not None and b"a" in row[c] for row in rows], dtype=bool)
+                return ("BITMAP", np.packbits(mask, bitorder="little") if n else np.zeros(0, np.uint8))
+            leaves.append(like)
+
+    def build(d):
+        if d == 0 or rng.random() < 0.3:
+            return [leaves[int(rng.integers(0, len(leaves)))]()]
+        k = rng.random()
+        if k < 0.2:
+            return build(d - 1) + [("NOT",)]
+        return build(d - 1) + build(d - 1) + [("AND",) if k < 0.6 else ("OR",)]
+
+    return build(depth)

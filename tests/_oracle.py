@@ -54,6 +54,7 @@ def lib():
         L.rjo_encode_fixed.restype = C.c_int
         L.rjo_encode_varchar.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
         L.rjo_encode_varchar.restype = C.c_int
+        L.rjo_from_csv.restype = C.c_int
         L.rjo_hash_int.argtypes = [C.c_int64]
         L.rjo_hash_int.restype = C.c_uint64
         L.rjo_num_buckets.argtypes = [C.c_uint64, C.c_uint64]
@@ -151,5 +152,35 @@ def encode_varchar(strings) -> pl.Column:
     assert rc == 0
     try:
         return _result_to_table(L, out).columns[0]
+    finally:
+        L.rjo_result_free(out)
+
+
+def from_csv(text: bytes, types, filt=None) -> "pl.ColumnarTable":
+    """The oracle's Table::from_csv (oracle/rjo_ingest.c): CSV text -> the filtered ColumnarTable,
+    pages filled by ColumnInserter's rule.  Raises RuntimeError with the reference's message."""
+    from pyrj import capi
+
+    L = lib()
+    n = len(types)
+    ct = (C.c_int32 * n)(*types)
+    ops, n_ops, keep = capi.filter_to_c(filt)
+    out = C.c_void_p()
+    err = C.create_string_buffer(256)
+    L.rjo_from_csv.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_int32), C.POINTER(capi.rj_filter_op), C.c_uint64,
+                               C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
+    rc = L.rjo_from_csv(text, len(text), n, ct, ops, n_ops, C.byref(out), err, 256)
+    del keep
+    if rc != 0:
+        raise RuntimeError(err.value.decode())
+    try:
+        cols = []
+        for c in range(n):
+            npg = int(L.rjo_result_col_pages(out, c))
+            pages = np.zeros((npg, pg.PAGE_SIZE), dtype=np.uint8)
+            for k in range(npg):
+                C.memmove(pages[k].ctypes.data, L.rjo_result_page(out, c, k), pg.PAGE_SIZE)
+            cols.append(pl.Column(int(L.rjo_result_col_type(out, c)), pages))
+        return pl.ColumnarTable(int(L.rjo_result_num_rows(out)), cols)
     finally:
         L.rjo_result_free(out)
