@@ -221,6 +221,8 @@ def load():
     L.rj_table_adopt_device.restype = C.c_int
     L.rj_table_release.argtypes = [vp, vp]
     L.rj_table_release.restype = None
+    L.rj_table_num_rows.argtypes = [vp]
+    L.rj_table_num_rows.restype = u64
     L.rj_execute.argtypes = [vp, C.POINTER(pl.rj_plan), C.POINTER(vp)]
     L.rj_execute.restype = C.c_int
     L.rj_execute_resident.argtypes = [vp, C.POINTER(pl.rj_plan), C.POINTER(vp), u64, i32, C.POINTER(vp)]
