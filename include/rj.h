@@ -186,12 +186,15 @@ void rj_table_release(rj_context* ctx, rj_table* t);
  * src/statement.cpp:46-135,186-201) — comparison and IS [NOT] NULL leaves push a row bitmap,
  * RJ_F_AND / RJ_F_OR pop two, RJ_F_NOT pops one; n_filter_ops == 0 keeps every row.  NULL
  * semantics are the reference's bitmap arithmetic: a comparison is false on NULL, NOT flips every
- * bit (so NOT (x < 5) holds for NULL x).  Predicates the device does not evaluate — LIKE /
- * NOT LIKE (RE2 in the reference, statement.h:118-161) and the other string comparisons — come in
- * as RJ_F_HOST_BITMAP leaves: bit r (LSB first) of host_bitmap = row r of the CSV passes.       */
+ * bit (so NOT (x < 5) holds for NULL x).  The one predicate the device does not evaluate — LIKE /
+ * NOT LIKE, which the reference hands to RE2 (statement.h:118-161: UTF-8 aware, '.' stops at a
+ * newline) — comes in as an RJ_F_HOST_BITMAP leaf: bit r (LSB first) of `bytes` = row r of the CSV
+ * passes.                                                                                       */
 typedef enum rj_filter_opcode {
-    RJ_F_EQ = 0, RJ_F_NEQ = 1, RJ_F_LT = 2, RJ_F_GT = 3, RJ_F_LEQ = 4, RJ_F_GEQ = 5, /* column <op> ivalue (INT32 / INT64 columns;
-                                        an INT32 column compares with (int32_t)ivalue: statement.cpp:55)        */
+    RJ_F_EQ = 0, RJ_F_NEQ = 1, RJ_F_LT = 2, RJ_F_GT = 3, RJ_F_LEQ = 4, RJ_F_GEQ = 5, /* column <op> literal.  INT32 / INT64
+                                        columns: ivalue (an INT32 column compares with (int32_t)ivalue: statement.cpp:55);
+                                        VARCHAR columns: the ivalue bytes at `bytes`, compared as std::string does
+                                        (unsigned bytes, then length: statement.cpp:117-126)                    */
     RJ_F_IS_NULL = 6, RJ_F_IS_NOT_NULL = 7,                   /* any column                                   */
     RJ_F_HOST_BITMAP = 8,
     RJ_F_AND = 9, RJ_F_OR = 10, RJ_F_NOT = 11
@@ -200,8 +203,9 @@ typedef enum rj_filter_opcode {
 typedef struct rj_filter_op {
     int32_t        op;          /* rj_filter_opcode */
     int32_t        column;      /* leaves */
-    int64_t        ivalue;      /* comparison leaves */
-    const uint8_t* host_bitmap; /* RJ_F_HOST_BITMAP: (rows + 7) / 8 bytes, rows = records of the CSV */
+    int64_t        ivalue;      /* comparison leaves: the literal, or the length of a string literal */
+    const uint8_t* bytes;       /* RJ_F_HOST_BITMAP: (rows + 7) / 8 bytes, rows = records of the CSV;
+                                   string comparison: the literal's bytes                            */
 } rj_filter_op;
 
 int rj_table_from_csv(rj_context* ctx, const char* text, uint64_t n_bytes, uint64_t n_cols,

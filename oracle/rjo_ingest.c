@@ -243,7 +243,7 @@ static int eval_filter(const rj_filter_op* ops, uint64_t n_ops, const icol* cols
             if (sp >= 64) return -1;
             int v = 0;
             if (o->op == RJ_F_HOST_BITMAP) {
-                v = o->host_bitmap ? (o->host_bitmap[r >> 3] >> (r & 7)) & 1 : 0;
+                v = o->bytes ? (o->bytes[r >> 3] >> (r & 7)) & 1 : 0;
             } else {
                 if (o->column < 0 || (uint64_t)o->column >= n_cols) return -1;
                 const icol* c = &cols[o->column];
@@ -252,7 +252,22 @@ static int eval_filter(const rj_filter_op* ops, uint64_t n_ops, const icol* cols
                     v = !nn;
                 else if (o->op == RJ_F_IS_NOT_NULL)
                     v = nn;
-                else {
+                else if (c->type == RJ_VARCHAR) { /* std::string comparison, statement.cpp:117-126 */
+                    const size_t la = c->soff[r + 1] - c->soff[r], lb = (size_t)o->ivalue, lm = la < lb ? la : lb;
+                    int          d = lm ? memcmp(c->heap + c->soff[r], o->bytes, lm) : 0;
+                    if (d == 0) d = la < lb ? -1 : (la > lb ? 1 : 0);
+                    int cmp = 0;
+                    switch (o->op) {
+                    case RJ_F_EQ: cmp = d == 0; break;
+                    case RJ_F_NEQ: cmp = d != 0; break;
+                    case RJ_F_LT: cmp = d < 0; break;
+                    case RJ_F_GT: cmp = d > 0; break;
+                    case RJ_F_LEQ: cmp = d <= 0; break;
+                    case RJ_F_GEQ: cmp = d >= 0; break;
+                    default: return -1;
+                    }
+                    v = nn & cmp;
+                } else {
                     if (c->type != RJ_INT32 && c->type != RJ_INT64) return -1;
                     const int64_t x = c->i[r], y = c->type == RJ_INT32 ? (int64_t)(int32_t)o->ivalue : o->ivalue; /* :55 */
                     int           cmp = 0;

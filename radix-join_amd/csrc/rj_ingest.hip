@@ -6,7 +6,7 @@
 //   CSVParser::execute / finish     src/csv_parser.cpp:3-175      k_csv_trans .. k_csv_emit
 //   TableParser::on_field           src/build_table.cpp:31-76     k_csv_ints, k_csv_strlen
 //   Comparison / LogicalOperation   src/statement.cpp:8-135,186-201 (over include/inner_column.h:
-//                                   170-324)                      k_ing_filter
+//                                   170-324, :372-516 for strings) k_ing_filter
 //   from_inner_to_column +          src/build_table.cpp:94-119,
 //   ColumnInserter<T>, <string>     include/plan.h:151-335        k_ing_next_*, k_ing_walk_*,
 //                                                                 k_ing_pages_fixed / _varchar
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void k_csv_strlen(const uint8_t* t, const uint
 struct DevFilterOp {
     int32_t        op, column;
     int64_t        ivalue;
-    const uint8_t* bitmap;  // RJ_F_HOST_BITMAP: device copy
+    const uint8_t* bytes;  // device copy of the host bitmap / the string literal
 };
 struct DevCol {
     const uint8_t*  values;  // INT32 / INT64
@@ -330,9 +330,11 @@ struct DevCol {
 };
 constexpr int MAX_FILTER_OPS = 64, MAX_ING_COLS = 64;
 struct FilterProg {
-    DevFilterOp ops[MAX_FILTER_OPS];
-    DevCol      cols[MAX_ING_COLS];
-    uint32_t    n_ops;
+    DevFilterOp     ops[MAX_FILTER_OPS];
+    DevCol          cols[MAX_ING_COLS];
+    uint32_t        n_ops, n_cols;
+    const uint8_t*  text;  // string comparisons decode the field itself
+    const uint32_t* fend;
 };
 // one row of the bitmap arithmetic of statement.cpp:8-135,186-201: comparisons are false on NULL
 // (inner_column.h:247-253: bitmap & cmp), NOT flips every bit, NULL rows included
@@ -355,7 +357,39 @@ __global__ __launch_bounds__(256) void k_ing_filter(const FilterProg* pp, uint32
         } else {
             uint64_t v = 0;
             if (o.op == RJ_F_HOST_BITMAP) {
-                v = (o.bitmap[r >> 3] >> (r & 7u)) & 1u;
+                v = (o.bytes[r >> 3] >> (r & 7u)) & 1u;
+            } else if (o.op <= RJ_F_GEQ && p.cols[o.column].type == RJ_VARCHAR) {
+                // std::string comparison (statement.cpp:117-126): unsigned bytes, then length
+                const DevCol& c = p.cols[o.column];
+                if (c.len[r] != NULL_LEN) {
+                    const Field f = field_of(p.text, p.fend, p.n_cols, r, (uint32_t)o.column);
+                    FieldChars  it{p.text, f.beg, f.end, 0};
+                    const uint32_t lb = (uint32_t)o.ivalue;
+                    int            d = 0;
+                    uint8_t        ch;
+                    uint32_t       k = 0;
+                    for (;; ++k) {
+                        const bool more = it.next(ch);
+                        if (!more || k >= lb) {
+                            d = more ? 1 : (k < lb ? -1 : 0);
+                            break;
+                        }
+                        if (ch != o.bytes[k]) {
+                            d = ch < o.bytes[k] ? -1 : 1;
+                            break;
+                        }
+                    }
+                    bool cmp;
+                    switch (o.op) {
+                    case RJ_F_EQ: cmp = d == 0; break;
+                    case RJ_F_NEQ: cmp = d != 0; break;
+                    case RJ_F_LT: cmp = d < 0; break;
+                    case RJ_F_GT: cmp = d > 0; break;
+                    case RJ_F_LEQ: cmp = d <= 0; break;
+                    default: cmp = d >= 0; break;
+                    }
+                    v = cmp;
+                }
             } else {
                 const DevCol& c = p.cols[o.column];
                 const bool    nn = c.type == RJ_VARCHAR ? c.len[r] != NULL_LEN : c.valid[r] != 0;
@@ -708,11 +742,11 @@ Table* table_from_csv(Context* ctx, const char* text, uint64_t n_bytes, uint64_t
                 depth -= 0;
             else if (o.op >= RJ_F_EQ && o.op <= RJ_F_HOST_BITMAP) {
                 if (o.op == RJ_F_HOST_BITMAP) {
-                    if (!o.host_bitmap) throw_fmt(RJ_ERR_ARG, "from_csv: host bitmap leaf without a bitmap");
+                    if (!o.bytes) throw_fmt(RJ_ERR_ARG, "from_csv: host bitmap leaf without a bitmap");
                 } else {
                     if (o.column < 0 || (uint64_t)o.column >= n_cols) throw_fmt(RJ_ERR_ARG, "from_csv: filter column out of range");
-                    if (o.op <= RJ_F_GEQ && col_type[o.column] == RJ_VARCHAR)
-                        throw_fmt(RJ_ERR_UNSUPPORTED, "from_csv: string comparisons come in as RJ_F_HOST_BITMAP leaves");
+                    if (o.op <= RJ_F_GEQ && col_type[o.column] == RJ_VARCHAR && (o.ivalue < 0 || o.ivalue > 0x7fffffff || (o.ivalue && !o.bytes)))
+                        throw_fmt(RJ_ERR_ARG, "from_csv: string literal without bytes");
                 }
                 depth += 1;
             } else
@@ -820,13 +854,20 @@ Table* table_from_csv(Context* ctx, const char* text, uint64_t n_bytes, uint64_t
     // ---- filter -> selection -> output row of every selected row
     std::vector<BufP> bitmaps;
     prog->n_ops = (uint32_t)n_filter_ops;
+    prog->n_cols = (uint32_t)n_cols;
+    prog->text = t;
+    prog->fend = fend->as<uint32_t>();
     for (uint64_t k = 0; k < n_filter_ops; ++k) {
         prog->ops[k] = DevFilterOp{filter[k].op, filter[k].column, filter[k].ivalue, nullptr};
-        if (filter[k].op == RJ_F_HOST_BITMAP) {
-            const size_t nb = ((size_t)n_rows + 7) / 8;
+        size_t nb = 0;  // bytes that travel with the leaf: a host bitmap, or a string literal
+        if (filter[k].op == RJ_F_HOST_BITMAP)
+            nb = ((size_t)n_rows + 7) / 8;
+        else if (filter[k].op <= RJ_F_GEQ && col_type[filter[k].column] == RJ_VARCHAR)
+            nb = (size_t)filter[k].ivalue;
+        if (nb) {
             bitmaps.push_back(ctx->buf(nb));
-            RJ_HIP(hipMemcpyAsync(bitmaps.back()->p, filter[k].host_bitmap, nb, hipMemcpyHostToDevice, ctx->stream));
-            prog->ops[k].bitmap = bitmaps.back()->as<uint8_t>();
+            RJ_HIP(hipMemcpyAsync(bitmaps.back()->p, filter[k].bytes, nb, hipMemcpyHostToDevice, ctx->stream));
+            prog->ops[k].bytes = bitmaps.back()->as<uint8_t>();
         }
     }
     BufP dprog = ctx->buf(sizeof(FilterProg));

@@ -56,7 +56,7 @@ class rj_tuples(C.Structure):
 
 
 class rj_filter_op(C.Structure):
-    _fields_ = [("op", C.c_int32), ("column", C.c_int32), ("ivalue", C.c_int64), ("host_bitmap", C.c_void_p)]
+    _fields_ = [("op", C.c_int32), ("column", C.c_int32), ("ivalue", C.c_int64), ("bytes", C.c_void_p)]
 
 
 # rj_filter_opcode (include/rj.h): a filter is a postfix program, e.g.
@@ -72,14 +72,18 @@ def filter_to_c(prog):
     for k, term in enumerate(prog):
         op = F_OPS[term[0]]
         arr[k].op = op
-        if op <= 5:
+        if op <= 5 and isinstance(term[2], (bytes, bytearray)):  # string literal
+            lit = np.frombuffer(bytes(term[2]) or b"\0", dtype=np.uint8).copy()
+            keep.append(lit)
+            arr[k].column, arr[k].ivalue, arr[k].bytes = int(term[1]), len(term[2]), lit.ctypes.data
+        elif op <= 5:
             arr[k].column, arr[k].ivalue = int(term[1]), int(term[2])
         elif op in (6, 7):
             arr[k].column = int(term[1])
         elif op == 8:
             bm = np.ascontiguousarray(term[1], dtype=np.uint8)
             keep.append(bm)
-            arr[k].host_bitmap = bm.ctypes.data
+            arr[k].bytes = bm.ctypes.data
     return arr, len(prog), keep
 
 

@@ -113,6 +113,15 @@ def random_filter(rng, rows, types, depth=3):
         elif ty == INT64:
             leaves.append(lambda c=c: (["LT", "GT", "LEQ", "GEQ"][int(rng.integers(0, 4))], c, int(rng.integers(-(2**62), 2**62))))
         else:
+            # string comparisons run on the device (std::string order: unsigned bytes, then length)
+            def strcmp(c=c):
+                pool = [row[c] for row in rows[:50] if row[c] is not None] or [b"k"]
+                lit = pool[int(rng.integers(0, len(pool)))]
+                if rng.random() < 0.5:
+                    lit = lit[: int(rng.integers(0, len(lit) + 1))] + (b"" if rng.random() < 0.5 else b"m")
+                return (["EQ", "NEQ", "LT", "GT", "LEQ", "GEQ"][int(rng.integers(0, 6))], c, lit)
+            leaves.append(strcmp)
+
             # a predicate the host evaluates (LIKE '%a%'): handed over as a bitmap
             def like(c=c):
                 mask = np.array([row[c] is not None and b"a" in row[c] for row in rows], dtype=bool)

@@ -111,9 +111,8 @@ def test_prefix_parse_literal_truncation_and_unsupported(ctx):
     with pytest.raises(capi.RjError) as e:
         ctx.from_csv(b"1.5\n", [pl.FP64])
     assert e.value.code == 5  # FP64 text is not parsed on the device
-    with pytest.raises(capi.RjError) as e:
-        ctx.from_csv(b"a\n", [VC], [("EQ", 0, 1)])
-    assert e.value.code == 5 and "HOST_BITMAP" in e.value.message
+    same_pages(ctx, b'abc\n"ab"\n\nabd\n"a,b"\nab\\\n', [VC], [("GEQ", 0, b"ab"), ("LT", 0, b"abd"), ("AND",)])
+    same_pages(ctx, b'abc\nab\n\n', [VC], [("EQ", 0, b"")])  # nothing equals the empty string: an empty field is NULL
     with pytest.raises(capi.RjError) as e:
         ctx.from_csv(b"1\n", [I32], [("AND",)])
     assert e.value.code == 1

@@ -172,6 +172,16 @@ def test_errors_as_the_reference_raises_them(text, types, msg):
     assert msg in str(e.value)
 
 
+def test_string_comparisons_follow_std_string():
+    text = b'abc\n"ab"\n\nabd\n"a,b"\n\xc3\xa9\n'
+    t = _oracle.from_csv(text, [VC], [("GEQ", 0, b"ab"), ("LT", 0, b"abd"), ("AND",)])
+    assert rows_of(t) == [(b"abc",), (b"ab",)]
+    t = _oracle.from_csv(text, [VC], [("GT", 0, b"abd")])  # bytes compare unsigned: 0xc3 > 'a'
+    assert rows_of(t) == [(b"\xc3\xa9",)]
+    t = _oracle.from_csv(text, [VC], [("NEQ", 0, b"abc")])  # false on NULL (bitmap & cmp)
+    assert len(rows_of(t)) == 4
+
+
 def test_from_chars_takes_a_prefix_and_the_int32_literal_is_truncated():
     t = _oracle.from_csv(b"12abc,-2147483648\n7,2147483647\n", [I32, I32])  # trailing garbage is ignored (std::from_chars)
     assert rows_of(t) == [(12, -(2**31)), (7, 2**31 - 1)]
