@@ -186,10 +186,9 @@ void rj_table_release(rj_context* ctx, rj_table* t);
  * src/statement.cpp:46-135,186-201) — comparison and IS [NOT] NULL leaves push a row bitmap,
  * RJ_F_AND / RJ_F_OR pop two, RJ_F_NOT pops one; n_filter_ops == 0 keeps every row.  NULL
  * semantics are the reference's bitmap arithmetic: a comparison is false on NULL, NOT flips every
- * bit (so NOT (x < 5) holds for NULL x).  The one predicate the device does not evaluate — LIKE /
- * NOT LIKE, which the reference hands to RE2 (statement.h:118-161: UTF-8 aware, '.' stops at a
- * newline) — comes in as an RJ_F_HOST_BITMAP leaf: bit r (LSB first) of `bytes` = row r of the CSV
- * passes.                                                                                       */
+ * bit (so NOT (x < 5) holds for NULL x).  Anything else a caller wants to filter by comes in as
+ * an RJ_F_HOST_BITMAP leaf, evaluated by the caller: bit r (LSB first) of `bytes` = row r of the
+ * CSV passes.                                                                                   */
 typedef enum rj_filter_opcode {
     RJ_F_EQ = 0, RJ_F_NEQ = 1, RJ_F_LT = 2, RJ_F_GT = 3, RJ_F_LEQ = 4, RJ_F_GEQ = 5, /* column <op> literal.  INT32 / INT64
                                         columns: ivalue (an INT32 column compares with (int32_t)ivalue: statement.cpp:55);
@@ -197,7 +196,12 @@ typedef enum rj_filter_opcode {
                                         (unsigned bytes, then length: statement.cpp:117-126)                    */
     RJ_F_IS_NULL = 6, RJ_F_IS_NOT_NULL = 7,                   /* any column                                   */
     RJ_F_HOST_BITMAP = 8,
-    RJ_F_AND = 9, RJ_F_OR = 10, RJ_F_NOT = 11
+    RJ_F_AND = 9, RJ_F_OR = 10, RJ_F_NOT = 11,
+    RJ_F_LIKE = 12, RJ_F_NOT_LIKE = 13  /* VARCHAR column LIKE / NOT LIKE the ivalue bytes at `bytes` ('%' any run,
+                                           '_' any one character) — what the reference asks RE2 for
+                                           (statement.h:118-161: '%' -> ".*", '_' -> ".", full match, UTF-8, '.'
+                                           never matches a newline); false on NULL, both of them
+                                           (inner_column.h:518-562); at most 63 pattern characters         */
 } rj_filter_opcode;
 
 typedef struct rj_filter_op {

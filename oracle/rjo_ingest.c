@@ -225,6 +225,81 @@ done:
     return rc;
 }
 
+/* Comparison::like_match (statement.h:118-161): the pattern becomes a regular expression — '%' ->
+ * ".*", '_' -> ".", every other character itself — that RE2 must match against the WHOLE string,
+ * with RE2's defaults: UTF-8 (a '.' is one well-formed UTF-8 sequence: 00-7F | C2-DF 80-BF |
+ * E0 A0-BF 80-BF | E1-EF 80-BF 80-BF | F0 90-BF 80-BF 80-BF | F1-F3 80-BF x3 | F4 80-8F 80-BF 80-BF)
+ * and no '.' for a newline.  Restated as a position-set automaton over the pattern's characters.
+ * A pattern that is not UTF-8 does not compile in RE2: like_match then returns false (:151-153).
+ * tok: 0x80000000 = '_', 0x80000001 = '%', else the character's bytes packed little-endian.       */
+static int utf8_unit(const unsigned char* s, size_t n, size_t* len, uint32_t* cp) {
+    if (!n) return 0;
+    unsigned char b0 = s[0];
+    size_t        L = 0;
+    unsigned char lo = 0x80, hi = 0xBF;
+    if (b0 < 0x80) L = 1;
+    else if (b0 >= 0xC2 && b0 <= 0xDF) L = 2;
+    else if (b0 == 0xE0) { L = 3; lo = 0xA0; }
+    else if (b0 >= 0xE1 && b0 <= 0xEF) L = 3;
+    else if (b0 == 0xF0) { L = 4; lo = 0x90; }
+    else if (b0 >= 0xF1 && b0 <= 0xF3) L = 4;
+    else if (b0 == 0xF4) { L = 4; hi = 0x8F; }
+    else return 0;
+    if (n < L) return 0;
+    uint32_t v = b0;
+    for (size_t k = 1; k < L; ++k) {
+        unsigned char b = s[k];
+        if (b < (k == 1 ? lo : 0x80) || b > (k == 1 ? hi : 0xBF)) return 0;
+        v |= (uint32_t)b << (8 * k);
+    }
+    *len = L;
+    *cp = v;
+    return 1;
+}
+/* -> number of tokens, or -1 (not UTF-8: never matches), or -2 (more than 63 characters) */
+static int like_compile(const unsigned char* pat, size_t n, uint32_t* tok) {
+    int m = 0;
+    for (size_t i = 0; i < n;) {
+        size_t   L;
+        uint32_t cp;
+        if (!utf8_unit(pat + i, n - i, &L, &cp)) return -1;
+        if (m >= 63) return -2;
+        tok[m++] = cp == '%' ? 0x80000001u : (cp == '_' ? 0x80000000u : cp);
+        i += L;
+    }
+    return m;
+}
+static int like_match(const uint32_t* tok, int m, const unsigned char* s, size_t n) {
+    if (m < 0) return 0;
+    uint64_t st = 1;
+#define LIKE_CLOSURE()                                                        \
+    for (int i_ = 0; i_ < m; ++i_)                                            \
+        if (((st >> i_) & 1) && tok[i_] == 0x80000001u) st |= 1ull << (i_ + 1)
+    LIKE_CLOSURE();
+    for (size_t i = 0; i < n;) {
+        size_t   L;
+        uint32_t cp;
+        if (!utf8_unit(s + i, n - i, &L, &cp)) return 0; /* no '.' and no literal takes ill-formed bytes */
+        uint64_t nx = 0;
+        for (int k = 0; k < m; ++k) {
+            if (!((st >> k) & 1)) continue;
+            if (tok[k] == 0x80000001u) {
+                if (cp != '\n') nx |= 1ull << k;
+            } else if (tok[k] == 0x80000000u) {
+                if (cp != '\n') nx |= 1ull << (k + 1);
+            } else if (tok[k] == cp) {
+                nx |= 1ull << (k + 1);
+            }
+        }
+        st = nx;
+        LIKE_CLOSURE();
+        if (!st) return 0;
+        i += L;
+    }
+#undef LIKE_CLOSURE
+    return (int)((st >> m) & 1);
+}
+
 /* Comparison::eval / LogicalOperation::eval (statement.cpp:46-135,186-201), one row at a time: the
  * reference computes whole bitmaps, bit r of which is what this returns for row r */
 static int eval_filter(const rj_filter_op* ops, uint64_t n_ops, const icol* cols, uint64_t n_cols, size_t r, int* out) {
@@ -252,7 +327,14 @@ static int eval_filter(const rj_filter_op* ops, uint64_t n_ops, const icol* cols
                     v = !nn;
                 else if (o->op == RJ_F_IS_NOT_NULL)
                     v = nn;
-                else if (c->type == RJ_VARCHAR) { /* std::string comparison, statement.cpp:117-126 */
+                else if (o->op == RJ_F_LIKE || o->op == RJ_F_NOT_LIKE) { /* inner_column.h:518-562 */
+                    if (c->type != RJ_VARCHAR) return -1;
+                    uint32_t tok[64];
+                    int      m = like_compile(o->bytes, (size_t)o->ivalue, tok);
+                    if (m == -2) return -1;
+                    int hit = nn ? like_match(tok, m, (const unsigned char*)c->heap + c->soff[r], c->soff[r + 1] - c->soff[r]) : 0;
+                    v = nn & (o->op == RJ_F_LIKE ? hit : !hit);
+                } else if (c->type == RJ_VARCHAR) { /* std::string comparison, statement.cpp:117-126 */
                     const size_t la = c->soff[r + 1] - c->soff[r], lb = (size_t)o->ivalue, lm = la < lb ? la : lb;
                     int          d = lm ? memcmp(c->heap + c->soff[r], o->bytes, lm) : 0;
                     if (d == 0) d = la < lb ? -1 : (la > lb ? 1 : 0);

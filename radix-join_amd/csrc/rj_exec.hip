@@ -478,6 +478,11 @@ class Exec {
                 n_groups = (uint32_t)((n + gt - 1) / gt);
             } else {
                     pp.tiles_per_group = tiles_per_group(n / nseg_in + 1, 16);
+                    // the last pass of 12-byte-tuple plans (one 384-byte-run output stream) does
+                    // better with short groups — 2 tiles per workgroup: 9.3-10.3 -> 8.9-9.1 ms per step
+                    // at 1 B rows; packed 8-byte tuples lose with them
+                    // (profiles/r03_l_later_pass_group_size_ab.log)
+                    if (P.aos3 && p + 1 == passes) pp.tiles_per_group = std::min<uint32_t>(pp.tiles_per_group, 2u);
                     uint64_t gt = (uint64_t)pp.tiles_per_group * PT_TILE;
                     if (ctx->tune.tpg2 > 0) {
                         pp.tiles_per_group = (uint32_t)ctx->tune.tpg2;

@@ -6,7 +6,7 @@
 //   CSVParser::execute / finish     src/csv_parser.cpp:3-175      k_csv_trans .. k_csv_emit
 //   TableParser::on_field           src/build_table.cpp:31-76     k_csv_ints, k_csv_strlen
 //   Comparison / LogicalOperation   src/statement.cpp:8-135,186-201 (over include/inner_column.h:
-//                                   170-324, :372-516 for strings) k_ing_filter
+//                                   170-324, :372-562 for strings; LIKE: statement.h:118-161) k_ing_filter
 //   from_inner_to_column +          src/build_table.cpp:94-119,
 //   ColumnInserter<T>, <string>     include/plan.h:151-335        k_ing_next_*, k_ing_walk_*,
 //                                                                 k_ing_pages_fixed / _varchar
@@ -316,11 +316,74 @@ __global__ __launch_bounds__(256) void k_csv_strlen(const uint8_t* t, const uint
     len[r] = n ? n : NULL_LEN;
 }
 
+// ------------------------------------------------------------------ LIKE
+// Comparison::like_match (reference include/statement.h:118-161): '%' -> ".*", '_' -> ".", every
+// other character itself, and RE2 must match the WHOLE string with its defaults — UTF-8 (a '.' is
+// one well-formed sequence) and no '.' for a newline.  A position-set automaton over the pattern's
+// characters (at most 63): bit i = "the first i pattern characters are matched".
+constexpr uint32_t LIKE_ANY = 0x80000000u, LIKE_RUN = 0x80000001u;
+// one well-formed UTF-8 sequence off the field's characters, packed little-endian; false = none
+__device__ __forceinline__ bool like_unit(FieldChars& it, uint32_t& cp, bool& bad) {
+    uint8_t b0;
+    if (!it.next(b0)) return false;
+    uint32_t L = 0, lo = 0x80, hi = 0xBF;
+    if (b0 < 0x80) L = 1;
+    else if (b0 >= 0xC2 && b0 <= 0xDF) L = 2;
+    else if (b0 == 0xE0) { L = 3; lo = 0xA0; }
+    else if (b0 >= 0xE1 && b0 <= 0xEF) L = 3;
+    else if (b0 == 0xF0) { L = 4; lo = 0x90; }
+    else if (b0 >= 0xF1 && b0 <= 0xF3) L = 4;
+    else if (b0 == 0xF4) { L = 4; hi = 0x8F; }
+    if (!L) {
+        bad = true;
+        return true;
+    }
+    cp = b0;
+    for (uint32_t k = 1; k < L; ++k) {
+        uint8_t b;
+        if (!it.next(b) || b < (k == 1 ? lo : 0x80u) || b > (k == 1 ? hi : 0xBFu)) {
+            bad = true;
+            return true;
+        }
+        cp |= (uint32_t)b << (8 * k);
+    }
+    return true;
+}
+__device__ __forceinline__ bool like_match(const uint32_t* tok, int m, FieldChars it) {
+    if (m < 0) return false;  // the pattern is not UTF-8: RE2 would not compile it (:151-153)
+    uint64_t st = 1;
+    auto     closure = [&] {
+        for (int i = 0; i < m; ++i)
+            if (((st >> i) & 1u) && tok[i] == LIKE_RUN) st |= 1ull << (i + 1);
+    };
+    closure();
+    uint32_t cp;
+    bool     bad = false;
+    while (like_unit(it, cp, bad)) {
+        if (bad) return false;  // neither '.' nor a literal takes ill-formed bytes
+        uint64_t nx = 0;
+        for (int k = 0; k < m; ++k) {
+            if (!((st >> k) & 1u)) continue;
+            const uint32_t t = tok[k];
+            if (t == LIKE_RUN)
+                nx |= (uint64_t)(cp != '\n') << k;
+            else if (t == LIKE_ANY)
+                nx |= (uint64_t)(cp != '\n') << (k + 1);
+            else
+                nx |= (uint64_t)(t == cp) << (k + 1);
+        }
+        st = nx;
+        closure();
+        if (!st) return false;
+    }
+    return (st >> m) & 1u;
+}
+
 // ------------------------------------------------------------------ filter
 struct DevFilterOp {
     int32_t        op, column;
     int64_t        ivalue;
-    const uint8_t* bytes;  // device copy of the host bitmap / the string literal
+    const uint8_t* bytes;  // device copy of the host bitmap / the string literal / the LIKE tokens (u32 each)
 };
 struct DevCol {
     const uint8_t*  values;  // INT32 / INT64
@@ -358,6 +421,12 @@ __global__ __launch_bounds__(256) void k_ing_filter(const FilterProg* pp, uint32
             uint64_t v = 0;
             if (o.op == RJ_F_HOST_BITMAP) {
                 v = (o.bytes[r >> 3] >> (r & 7u)) & 1u;
+            } else if (o.op == RJ_F_LIKE || o.op == RJ_F_NOT_LIKE) {  // false on NULL, both (inner_column.h:518-562)
+                if (p.cols[o.column].len[r] != NULL_LEN) {
+                    const Field f = field_of(p.text, p.fend, p.n_cols, r, (uint32_t)o.column);
+                    const bool  hit = like_match(reinterpret_cast<const uint32_t*>(o.bytes), (int)o.ivalue, FieldChars{p.text, f.beg, f.end, 0});
+                    v = o.op == RJ_F_LIKE ? hit : !hit;
+                }
             } else if (o.op <= RJ_F_GEQ && p.cols[o.column].type == RJ_VARCHAR) {
                 // std::string comparison (statement.cpp:117-126): unsigned bytes, then length
                 const DevCol& c = p.cols[o.column];
@@ -740,7 +809,12 @@ Table* table_from_csv(Context* ctx, const char* text, uint64_t n_bytes, uint64_t
                 depth -= 1;
             else if (o.op == RJ_F_NOT)
                 depth -= 0;
-            else if (o.op >= RJ_F_EQ && o.op <= RJ_F_HOST_BITMAP) {
+            else if (o.op == RJ_F_LIKE || o.op == RJ_F_NOT_LIKE) {
+                if (o.column < 0 || (uint64_t)o.column >= n_cols || col_type[o.column] != RJ_VARCHAR)
+                    throw_fmt(RJ_ERR_ARG, "from_csv: LIKE wants a VARCHAR column");
+                if (o.ivalue < 0 || o.ivalue > 4 * 63 || (o.ivalue && !o.bytes)) throw_fmt(RJ_ERR_UNSUPPORTED, "from_csv: LIKE pattern too long");
+                depth += 1;
+            } else if (o.op >= RJ_F_EQ && o.op <= RJ_F_HOST_BITMAP) {
                 if (o.op == RJ_F_HOST_BITMAP) {
                     if (!o.bytes) throw_fmt(RJ_ERR_ARG, "from_csv: host bitmap leaf without a bitmap");
                 } else {
@@ -860,6 +934,45 @@ Table* table_from_csv(Context* ctx, const char* text, uint64_t n_bytes, uint64_t
     for (uint64_t k = 0; k < n_filter_ops; ++k) {
         prog->ops[k] = DevFilterOp{filter[k].op, filter[k].column, filter[k].ivalue, nullptr};
         size_t nb = 0;  // bytes that travel with the leaf: a host bitmap, or a string literal
+        if (filter[k].op == RJ_F_LIKE || filter[k].op == RJ_F_NOT_LIKE) {
+            // the pattern, one token per character ('%' / '_' / the character's UTF-8 bytes packed)
+            std::vector<uint32_t> tok;
+            const uint8_t*        pat = filter[k].bytes;
+            const size_t          pn = (size_t)filter[k].ivalue;
+            bool                  utf8 = true;
+            for (size_t i = 0; i < pn && utf8;) {
+                const uint8_t b0 = pat[i];
+                size_t        len = 0;
+                uint8_t       lo = 0x80, hi = 0xBF;
+                if (b0 < 0x80) len = 1;
+                else if (b0 >= 0xC2 && b0 <= 0xDF) len = 2;
+                else if (b0 == 0xE0) { len = 3; lo = 0xA0; }
+                else if (b0 >= 0xE1 && b0 <= 0xEF) len = 3;
+                else if (b0 == 0xF0) { len = 4; lo = 0x90; }
+                else if (b0 >= 0xF1 && b0 <= 0xF3) len = 4;
+                else if (b0 == 0xF4) { len = 4; hi = 0x8F; }
+                if (!len || i + len > pn) {
+                    utf8 = false;
+                    break;
+                }
+                uint32_t cp = b0;
+                for (size_t q = 1; q < len; ++q) {
+                    const uint8_t b = pat[i + q];
+                    if (b < (q == 1 ? lo : 0x80) || b > (q == 1 ? hi : 0xBF)) utf8 = false;
+                    cp |= (uint32_t)b << (8 * q);
+                }
+                tok.push_back(cp == '%' ? LIKE_RUN : (cp == '_' ? LIKE_ANY : cp));
+                i += len;
+            }
+            if (utf8 && tok.size() > 63) throw_fmt(RJ_ERR_UNSUPPORTED, "from_csv: LIKE pattern of more than 63 characters");
+            prog->ops[k].ivalue = utf8 ? (int64_t)tok.size() : -1;
+            if (utf8 && !tok.empty()) {
+                bitmaps.push_back(ctx->buf(tok.size() * 4));
+                RJ_HIP(hipMemcpy(bitmaps.back()->p, tok.data(), tok.size() * 4, hipMemcpyHostToDevice));
+                prog->ops[k].bytes = bitmaps.back()->as<uint8_t>();
+            }
+            continue;
+        }
         if (filter[k].op == RJ_F_HOST_BITMAP)
             nb = ((size_t)n_rows + 7) / 8;
         else if (filter[k].op <= RJ_F_GEQ && col_type[filter[k].column] == RJ_VARCHAR)

@@ -61,7 +61,7 @@ class rj_filter_op(C.Structure):
 
 # rj_filter_opcode (include/rj.h): a filter is a postfix program, e.g.
 #   [("LT", 2, 1990), ("IS_NULL", 4), ("NOT",), ("AND",), ("BITMAP", np.packbits(mask, bitorder="little")), ("OR",)]
-F_OPS = {"EQ": 0, "NEQ": 1, "LT": 2, "GT": 3, "LEQ": 4, "GEQ": 5, "IS_NULL": 6, "IS_NOT_NULL": 7, "BITMAP": 8, "AND": 9, "OR": 10, "NOT": 11}
+F_OPS = {"EQ": 0, "NEQ": 1, "LT": 2, "GT": 3, "LEQ": 4, "GEQ": 5, "IS_NULL": 6, "IS_NOT_NULL": 7, "BITMAP": 8, "AND": 9, "OR": 10, "NOT": 11, "LIKE": 12, "NOT_LIKE": 13}
 
 
 def filter_to_c(prog):
@@ -72,7 +72,7 @@ def filter_to_c(prog):
     for k, term in enumerate(prog):
         op = F_OPS[term[0]]
         arr[k].op = op
-        if op <= 5 and isinstance(term[2], (bytes, bytearray)):  # string literal
+        if (op <= 5 or op >= 12) and isinstance(term[2], (bytes, bytearray)):  # string literal / LIKE pattern
             lit = np.frombuffer(bytes(term[2]) or b"\0", dtype=np.uint8).copy()
             keep.append(lit)
             arr[k].column, arr[k].ivalue, arr[k].bytes = int(term[1]), len(term[2]), lit.ctypes.data

@@ -74,6 +74,19 @@ def to_csv(rng, rows, crlf_p=0.2, final_newline=True):
     return bytes(out)
 
 
+def like_model(text: bytes, pattern: bytes) -> bool:
+    """what the reference asks RE2 for (statement.h:118-161), through Python's re on well-formed
+    UTF-8: '%' -> '.*', '_' -> '.', full match, '.' stops at a newline"""
+    import re
+
+    try:
+        t, p = text.decode("utf-8"), pattern.decode("utf-8")
+    except UnicodeDecodeError:
+        return False  # ill-formed text matches nothing; an ill-formed pattern does not compile
+    rx = "".join(".*" if ch == "%" else "." if ch == "_" else re.escape(ch) for ch in p)
+    return re.fullmatch(rx, t) is not None
+
+
 def eval_filter(prog, row, r):
     """row-level twin of the reference's bitmap arithmetic (statement.cpp:8-135,186-201)"""
     if not prog:
@@ -88,6 +101,10 @@ def eval_filter(prog, row, r):
             st.append(not st.pop())
         elif op == "BITMAP":
             st.append(bool((term[1][r >> 3] >> (r & 7)) & 1))
+        elif op in ("LIKE", "NOT_LIKE"):
+            x = row[term[1]]
+            hit = x is not None and like_model(x, term[2])
+            st.append(x is not None and (hit if op == "LIKE" else not hit))
         elif op == "IS_NULL":
             st.append(row[term[1]] is None)
         elif op == "IS_NOT_NULL":
@@ -122,7 +139,24 @@ def random_filter(rng, rows, types, depth=3):
                 return (["EQ", "NEQ", "LT", "GT", "LEQ", "GEQ"][int(rng.integers(0, 6))], c, lit)
             leaves.append(strcmp)
 
-            # a predicate the host evaluates (LIKE '%a%'): handed over as a bitmap
+            def like_dev(c=c):
+                pool = [row[c] for row in rows[:80] if row[c] is not None and len(row[c]) < 60] or [b"abc"]
+                src = pool[int(rng.integers(0, len(pool)))]
+                pat = bytearray()
+                for ch in src[: int(rng.integers(1, 12))]:
+                    x = rng.random()
+                    if x < 0.2:
+                        pat += b"%"
+                    elif x < 0.3:
+                        pat += b"_"
+                    elif ch not in b"%_":
+                        pat.append(ch)
+                if rng.random() < 0.7:
+                    pat += b"%"
+                return (["LIKE", "NOT_LIKE"][int(rng.integers(0, 2))], c, bytes(pat))
+            leaves.append(like_dev)
+
+            # a predicate the caller evaluates itself (here: contains an 'a'): handed over as a bitmap
             def like(c=c):
                 mask = np.array([row[c] is not None and b"a" in row[c] for row in rows], dtype=bool)
                 return ("BITMAP", np.packbits(mask, bitorder="little") if n else np.zeros(0, np.uint8))

@@ -118,6 +118,20 @@ def test_prefix_parse_literal_truncation_and_unsupported(ctx):
     assert e.value.code == 1
 
 
+def test_like_on_the_device(ctx):
+    rows = [b"abc", b"abcd", b"xbc", None, b"a\nc", "\u00e9t\u00e9".encode(), b"a\xffc", b"%", b"a.c", b"ac", "\U0001f600x".encode()]
+    text = b"".join((b'"' + r.replace(b'"', b'\\"') + b'"' if r is not None else b"") + b"\n" for r in rows) * 50
+    for pat in (b"a%", b"a_c", b"_bc%", "_t_".encode(), "\u00e9%".encode(), b"a.c", b"\xff%", b"%", b"%c", b"%b%", b"_%_", b"a%c%", b"%%a", b"_x", b""):
+        same_pages(ctx, text, [VC], [("LIKE", 0, pat)])
+        same_pages(ctx, text, [VC], [("NOT_LIKE", 0, pat), ("IS_NOT_NULL", 0), ("AND",)])
+    with pytest.raises(capi.RjError) as e:
+        ctx.from_csv(b"1\n", [I32], [("LIKE", 0, b"1%")])
+    assert e.value.code == 1
+    with pytest.raises(capi.RjError) as e:
+        ctx.from_csv(b"a\n", [VC], [("LIKE", 0, b"a" * 64)])
+    assert e.value.code == 5
+
+
 def test_join_over_tables_ingested_on_the_device(ctx):
     """title-like and cast-like tables arrive as CSV text, are filtered and packed on the device, and
     the resident tables go straight into rj_execute_resident: nothing is uploaded at execute() time.

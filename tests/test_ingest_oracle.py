@@ -182,6 +182,31 @@ def test_string_comparisons_follow_std_string():
     assert len(rows_of(t)) == 4
 
 
+def test_like_is_what_re2_is_asked_for():
+    """'%' any run, '_' any ONE character — a UTF-8 character, never a newline; the whole string must
+    match; NULL is false for LIKE and for NOT LIKE; ill-formed UTF-8 matches nothing (so NOT LIKE
+    holds for it)"""
+    rows = [b"abc", b"abcd", b"xbc", None, b"a\nc", "\u00e9t\u00e9".encode(), b"a\xffc", b"%", b"a.c", b"ac"]
+    text = b"".join((b'"' + r.replace(b'"', b'\\"') + b'"' if r is not None else b"") + b"\n" for r in rows)
+    def run(prog):
+        return [r[0] for r in rows_of(_oracle.from_csv(text, [VC], prog))]
+    assert run([("LIKE", 0, b"a%")]) == [b"abc", b"abcd", b"a.c", b"ac"]  # 'a\nc': '.' stops at the newline; 'a\xffc': ill-formed
+    assert run([("LIKE", 0, b"a_c")]) == [b"abc", b"a.c"]
+    assert run([("LIKE", 0, b"_bc%")]) == [b"abc", b"abcd", b"xbc"]
+    assert run([("LIKE", 0, "_t_".encode())]) == ["\u00e9t\u00e9".encode()]  # '_' is one CHARACTER, two bytes here
+    assert run([("LIKE", 0, "\u00e9%".encode())]) == ["\u00e9t\u00e9".encode()]
+    assert run([("LIKE", 0, b"a.c")]) == [b"a.c"]  # regex metacharacters are literals
+    assert run([("NOT_LIKE", 0, b"a%")]) == [b"xbc", b"a\nc", "\u00e9t\u00e9".encode(), b"a\xffc", b"%"]  # not the NULL row
+    assert run([("LIKE", 0, b"\xff%")]) == []  # a pattern that is not UTF-8 does not compile: false ...
+    assert len(run([("NOT_LIKE", 0, b"\xff%")])) == 9  # ... so NOT LIKE holds for every non-NULL row
+    assert run([("LIKE", 0, b"%")]) == [r for r in rows if r is not None and b"\n" not in r and b"\xff" not in r]
+    for r in rows:
+        for pat in (b"a%", b"%c", b"a_c", b"%b%", b"_%_", b"abc", b"a%c%", b"%%a", b"_"):
+            if r is not None:
+                got = run([("LIKE", 0, pat)])
+                assert (r in got) == g.like_model(r, pat), (r, pat)
+
+
 def test_from_chars_takes_a_prefix_and_the_int32_literal_is_truncated():
     t = _oracle.from_csv(b"12abc,-2147483648\n7,2147483647\n", [I32, I32])  # trailing garbage is ignored (std::from_chars)
     assert rows_of(t) == [(12, -(2**31)), (7, 2**31 - 1)]
