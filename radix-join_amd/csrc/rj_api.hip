@@ -86,7 +86,8 @@ int rj_context_create(rj_context** out, const rj_config* cfg) {
             std::vector<Context*> lanes;
             for (int i = 0; i < c->n_lanes(); ++i) lanes.push_back(c->lane(i));
             c->comm.reset(new Comm(lanes, world, cfg ? cfg->rank_base : 0, cfg ? cfg->exchange : 0,
-                                   cfg ? cfg->comm_id : nullptr, c->tune.exchange_timeout_ms));
+                                   cfg ? cfg->comm_id : nullptr, c->tune.exchange_timeout_ms,
+                                   c->tune.bringup_timeout_ms));
         }
         if (cfg && (cfg->flags & RJ_CTX_PREWARM))
             for (int i = 0; i < c->n_lanes(); ++i) c->lane(i)->prewarm();

@@ -183,15 +183,15 @@ void Comm::mark_failed(const char* what, const char* why) {
     }
 }
 
-void Comm::fail(const char* what, const char* why) {
+void Comm::fail(const char* what, const char* why, int ms) {
     mark_failed(what, why);
     throw_fmt(RJ_ERR_DEVICE,
-              "sharded join, rank %d: %s %s within %d ms (RJ_EXCHANGE_TIMEOUT_MS) — a peer rank failed, hangs or "
+              "sharded join, rank %d: %s %s within %d ms (%s) — a peer rank failed, hangs or "
               "never started; the job is lost, this process should exit",
-              rank_base_, what, why, timeout_ms_);
+              rank_base_, what, why, ms ? ms : timeout_ms_, ms ? "RJ_BRINGUP_TIMEOUT_MS" : "RJ_EXCHANGE_TIMEOUT_MS");
 }
 
-void Comm::bounded(const char* what, std::function<void()> fn) {
+void Comm::bounded(const char* what, std::function<void()> fn, int ms) {
     check_alive();
     if (!worker_) {
         worker_ = std::make_shared<Worker>();
@@ -204,7 +204,7 @@ void Comm::bounded(const char* what, std::function<void()> fn) {
     w.done = false;
     w.err = nullptr;
     w.cv.notify_all();
-    const auto deadline = Clock::now() + std::chrono::milliseconds(timeout_ms_);
+    const auto deadline = Clock::now() + std::chrono::milliseconds(ms ? ms : timeout_ms_);
     if (!w.cv.wait_until(lk, deadline, [&] { return w.done; })) {
         lk.unlock();
         mark_failed(what, "did not return");  // aborts the communicators: the blocked call then errors out
@@ -218,7 +218,7 @@ void Comm::bounded(const char* what, std::function<void()> fn) {
         } else {
             lk.unlock();
         }
-        fail(what, "did not return");
+        fail(what, "did not return", ms);
     }
     std::exception_ptr e = w.err;
     lk.unlock();
@@ -261,7 +261,8 @@ void Comm::make_id(rj_comm_id* out) {
     memcpy(out->bytes, id.internal, RJ_COMM_ID_BYTES);
 }
 
-Comm::Comm(std::vector<Context*> lanes, int world, int rank_base, int mode, const rj_comm_id* id, int timeout_ms)
+Comm::Comm(std::vector<Context*> lanes, int world, int rank_base, int mode, const rj_comm_id* id, int timeout_ms,
+           int bringup_ms)
     : lanes_(std::move(lanes)), world_(world), rank_base_(rank_base) {
     const int nl = (int)lanes_.size();
     if (timeout_ms > 0) timeout_ms_ = timeout_ms;
@@ -328,7 +329,7 @@ Comm::Comm(std::vector<Context*> lanes, int world, int rank_base, int mode, cons
                     (*slots)[l] = c;
                 }
                 if (nl > 1) RJ_NCCL(R.GroupEnd());
-            });
+            }, bringup_ms);
         } catch (...) {
             for (int l = 0; l < nl; ++l) {
                 (void)hipSetDevice(lanes_[l]->device);
@@ -383,7 +384,12 @@ void Comm::allgather_u64(const std::vector<std::vector<uint64_t>>& vals, size_t 
         return;
     }
     Rccl& R = rccl();
-    const size_t need = (size_t)(world_ + 1) * k * 8;
+    // Sized once for the largest tensor a join gathers (2 sides x 512 stage-A partitions + a status
+    // word): growing the buffers later would take a hipFree, which waits for EVERY stream of the
+    // device — stage A's scatters, which the exchange is to overlap — and, behind a stalled stream,
+    // would sit there without a bound.
+    const size_t kcap = std::max<size_t>(k, 2 * 512 + 1);
+    const size_t need = (size_t)(world_ + 1) * kcap * 8;
     if (need > cnt_cap_) {
         for (int l = 0; l < nl; ++l) {
             RJ_HIP(hipSetDevice(lanes_[l]->device));
@@ -393,19 +399,16 @@ void Comm::allgather_u64(const std::vector<std::vector<uint64_t>>& vals, size_t 
         }
         if (cnt_host_) RJ_HIP(hipHostFree(cnt_host_));
         cnt_host_ = nullptr;
-        RJ_HIP(hipHostMalloc(&cnt_host_, need, hipHostMallocDefault));
+        RJ_HIP(hipHostMalloc(&cnt_host_, (size_t)(world_ + nl) * kcap * 8, hipHostMallocDefault));
         cnt_cap_ = need;
     }
-    // (pinned both ways: nothing here may block the host behind a stalled stream)
+    // (pinned both ways and on the exchange streams: a synchronous copy, or one from pageable
+    // memory, would make the host wait behind the compute streams)
     uint64_t* hin = static_cast<uint64_t*>(cnt_host_) + (size_t)world_ * k;
     for (int l = 0; l < nl; ++l) {
         RJ_HIP(hipSetDevice(lanes_[l]->device));
-        if (l == 0) {
-            memcpy(hin, vals[l].data(), k * 8);
-            RJ_HIP(hipMemcpyAsync(cnt_dev_[l], hin, k * 8, hipMemcpyHostToDevice, xfer_[l]));
-        } else {
-            RJ_HIP(hipMemcpy(cnt_dev_[l], vals[l].data(), k * 8, hipMemcpyHostToDevice));
-        }
+        memcpy(hin + (size_t)l * k, vals[l].data(), k * 8);
+        RJ_HIP(hipMemcpyAsync(cnt_dev_[l], hin + (size_t)l * k, k * 8, hipMemcpyHostToDevice, xfer_[l]));
     }
     bounded("count all-gather (ncclAllGather)", [&] {
         if (nl > 1) RJ_NCCL(R.GroupStart());

@@ -49,8 +49,10 @@ class Comm {
    public:
     enum Mode { P2P = 1, RCCL = 2 };
     // lanes: the contexts of the local ranks (rank_base + i); world = ranks of the whole job;
-    // timeout_ms: the bound on every wait (bring-up included)
-    Comm(std::vector<Context*> lanes, int world, int rank_base, int mode, const rj_comm_id* id, int timeout_ms);
+    // timeout_ms: the bound on every wait; bringup_ms (0 = the same): the bound on communicator
+    // bring-up alone, which in a cold process (RCCL loading its kernels) can take seconds
+    Comm(std::vector<Context*> lanes, int world, int rank_base, int mode, const rj_comm_id* id, int timeout_ms,
+         int bringup_ms = 0);
     ~Comm();
     int  world() const { return world_; }
     int  rank_base() const { return rank_base_; }
@@ -101,9 +103,9 @@ class Comm {
     // helper thread for host calls that may block on a peer
     struct Worker;
     std::shared_ptr<Worker> worker_;
-    void bounded(const char* what, std::function<void()> fn);
+    void bounded(const char* what, std::function<void()> fn, int ms = 0);
     void mark_failed(const char* what, const char* why);  // aborts the communicators; does not throw
-    [[noreturn]] void fail(const char* what, const char* why);
+    [[noreturn]] void fail(const char* what, const char* why, int ms = 0);
     void check_alive() const;
 };
 

@@ -34,6 +34,7 @@ void Tuning::from_env() {
     wide_carry = env_int("RJ_TUNE_WIDE_CARRY", wide_carry);
     fold_owner = env_int("RJ_TUNE_FOLD_OWNER", fold_owner);
     exchange_timeout_ms = env_int("RJ_EXCHANGE_TIMEOUT_MS", exchange_timeout_ms);
+    bringup_timeout_ms = env_int("RJ_BRINGUP_TIMEOUT_MS", bringup_timeout_ms);
     debug_shard_fail = env_int("RJ_DEBUG_SHARD_FAIL", debug_shard_fail);
     debug_shard_fail_rank = env_int("RJ_DEBUG_SHARD_FAIL_RANK", debug_shard_fail_rank);
 }

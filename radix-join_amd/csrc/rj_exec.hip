@@ -1540,8 +1540,8 @@ class ShardedExec {
             Parted                P;       // stage B partitions
         };
         std::vector<SideX> bx((size_t)nl_), px((size_t)nl_);
-        if (((size_t)FA + 1) * 4 > Context::SMALL_PINNED / 2)
-            throw_fmt(RJ_ERR_UNSUPPORTED, "sharded join: more than %zu stage-A partitions", Context::SMALL_PINNED / 8 - 1);
+        if (((size_t)FA + 1) * 4 > Context::SMALL_PINNED / 4)
+            throw_fmt(RJ_ERR_UNSUPPORTED, "sharded join: more than %zu stage-A partitions", Context::SMALL_PINNED / 16 - 1);
         for (int l = 0; l < nl_; ++l) {
             guarded(lerr[l], [&] {
                 use(l);
@@ -1558,7 +1558,9 @@ class ShardedExec {
                     // the per-partition offsets leave for the host BEFORE the scatter is enqueued: the
                     // host sizes and starts the exchange of the build side while the probe side's
                     // scatter is still running
-                    uint32_t* host_off = static_cast<uint32_t*>(c->small_pinned()) + (size_t)side * (Context::SMALL_PINNED / 8);
+                    // (pinned block: [0, 1/4) and [1/4, 1/2) = the two sides' stage-A offsets, [1/2, 3/4) and
+                    // [3/4, 1) = their exchanged-run tables, below)
+                    uint32_t* host_off = static_cast<uint32_t*>(c->small_pinned()) + (size_t)side * (Context::SMALL_PINNED / 16);
                     const std::function<void(const uint32_t*)> counts_out = [&](const uint32_t* off) {
                         RJ_HIP(hipMemcpyAsync(host_off, off, ((size_t)FA + 1) * 4, hipMemcpyDeviceToHost, c->stream));
                         RJ_HIP(hipEventRecord(X.counted.e, c->stream));
@@ -1572,6 +1574,10 @@ class ShardedExec {
                     const uint32_t shiftA = sbits ? 0u : (rb_ ? 32 - rb_ : 31);
                     X.A = E.partition(&src, nullptr, KW, s.CW, rb_ + sbits, shiftA, /*single pass*/ true, nullptr, &counts_out,
                                       shape.hi_shift ? &shape : nullptr);
+                    // (test hook: this rank's probe-side slices are "never" ready — 7 s — so that the
+                    // bounded wait for their exchange can be seen to expire; the counts left earlier)
+                    if (g_->tune.debug_shard_fail == 4 && g_->tune.debug_shard_fail_rank == rank_base_ + l && side == 1)
+                        launch_debug_stall(E.L, 7000);
                     RJ_HIP(hipEventRecord(X.ready.e, c->stream));
                 }
             });
@@ -1586,7 +1592,7 @@ class ShardedExec {
                 for (int side = 0; side < 2; ++side) {
                     SideX& X = side == 0 ? bx[l] : px[l];
                     RJ_HIP(hipEventSynchronize(X.counted.e));  // (this rank's own stream: finite)
-                    const uint32_t* off = static_cast<const uint32_t*>(c->small_pinned()) + (size_t)side * (Context::SMALL_PINNED / 8);
+                    const uint32_t* off = static_cast<const uint32_t*>(c->small_pinned()) + (size_t)side * (Context::SMALL_PINNED / 16);
                     for (size_t q = 0; q < per_side; ++q) mine[l][side * per_side + q] = off[q + 1] - off[q];
                 }
             });
@@ -1631,13 +1637,17 @@ class ShardedExec {
                         X.ws.w.w[a] = X.recv[a]->as<uint32_t>();
                     }
                     if (S > 1) {  // the runs that arrive, as input segments of stage B's first pass
-                        const size_t ns = X.plan.seg_begin.size();
-                        X.segs = c->buf((2 * ns + S + 1) * 4);
-                        uint32_t* d = X.segs->as<uint32_t>();
-                        RJ_HIP(hipMemcpyAsync(d, X.plan.seg_begin.data(), ns * 4, hipMemcpyHostToDevice, c->stream));
-                        RJ_HIP(hipMemcpyAsync(d + ns, X.plan.seg_end.data(), ns * 4, hipMemcpyHostToDevice, c->stream));
-                        RJ_HIP(hipMemcpyAsync(d + 2 * ns, X.plan.part_off.data(), ((size_t)S + 1) * 4, hipMemcpyHostToDevice,
-                                              c->stream));
+                        // (through PINNED memory: an asynchronous copy from pageable memory makes the
+                        // host wait for everything queued on the stream — stage A's scatters — and the
+                        // exchange, which is to overlap them, would not even be enqueued until then)
+                        const size_t ns = X.plan.seg_begin.size(), words = 2 * ns + S + 1;
+                        if (words * 4 > Context::SMALL_PINNED / 4) throw_fmt(RJ_ERR_UNSUPPORTED, "sharded join: too many exchanged runs");
+                        uint32_t* h = static_cast<uint32_t*>(c->small_pinned()) + Context::SMALL_PINNED / 8 + (size_t)side * (Context::SMALL_PINNED / 16);
+                        std::copy(X.plan.seg_begin.begin(), X.plan.seg_begin.end(), h);
+                        std::copy(X.plan.seg_end.begin(), X.plan.seg_end.end(), h + ns);
+                        std::copy(X.plan.part_off.begin(), X.plan.part_off.end(), h + 2 * ns);
+                        X.segs = c->buf(words * 4);
+                        RJ_HIP(hipMemcpyAsync(X.segs->p, h, words * 4, hipMemcpyHostToDevice, c->stream));
                     }
                 }
             });

@@ -194,8 +194,11 @@ struct Tuning {
                           // in one pass; 0: by owner rank only (stage B then runs one more pass)
     int exchange_timeout_ms = 120000;  // RJ_EXCHANGE_TIMEOUT_MS: bound on every wait of the exchange step of a
                                        // sharded join (communicator bring-up, count gathers, the all-to-all)
+    int bringup_timeout_ms = 0;        // RJ_BRINGUP_TIMEOUT_MS: its own bound for the bring-up (0: the same) — in a
+                                       // cold process RCCL takes seconds to load, a running exchange milliseconds
     // RJ_DEBUG_SHARD_FAIL (tests): global rank RJ_DEBUG_SHARD_FAIL_RANK fails locally at this point of a
-    // sharded join — 1: while preparing, 2: in stage A, 3: allocating its receive buffers
+    // sharded join — 1: while preparing, 2: in stage A, 3: allocating its receive buffers; 4: it does not
+    // fail but stalls (its probe-side slices are not ready for 7 s: the exchange's bounded wait expires)
     int debug_shard_fail = 0, debug_shard_fail_rank = 0;
     void from_env();
 };
@@ -213,7 +216,7 @@ struct Context {
     // pinned staging for H2D / D2H of page images
     void*  pinned = nullptr;
     size_t pinned_bytes = 0;
-    static constexpr size_t SMALL_PINNED = 16384;
+    static constexpr size_t SMALL_PINNED = 32768;
     void*  pinned_small = nullptr;  // SMALL_PINNED bytes for counters that travel to the host
     void*  small_pinned();
     // second lane (rj_execute): inputs are uploaded by a helper thread on their own stream

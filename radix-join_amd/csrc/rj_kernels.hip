@@ -2366,6 +2366,14 @@ __global__ __launch_bounds__(256) void k_split_records(SplitParams sp, uint64_t 
     }
 }
 
+// Test hook (RJ_DEBUG_SHARD_FAIL=4): holds a stream for `ticks` of the constant-rate wall clock
+// (hipDeviceAttributeWallClockRate) — a rank whose stage A "never finishes", so that its peers'
+// bounded waits can be seen to expire.  Every wave leaves on its own when the time is up.
+__global__ void k_debug_stall(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(127);
+}
+
 // ================================================================== launchers
 // A rejected launch (LDS or launch-bounds mismatch of a tuning variant, wrong device) must not
 // pass silently: the stream would "succeed" and the join return stale buffers with RJ_OK.
@@ -2758,6 +2766,13 @@ void launch_join_bcast(const Launch& L, int key_words, int cw_build, int cw_prob
     case 222: join_bcast_t<2, 2, 2>(L, bp, grid); break;
     default: launch_failed("join_broadcast", "no kernel for this key/carry word count", true);
     }
+}
+
+void launch_debug_stall(const Launch& L, uint32_t ms) {
+    int dev = 0, khz = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;
+    RJ_KLAUNCH(L, "debug_stall", k_debug_stall, 1, 64, (unsigned long long)ms * (unsigned long long)khz);
 }
 
 void launch_pack_validity(const Launch& L, const uint8_t* v0, const uint8_t* v1, const uint8_t* v2, uint32_t n,

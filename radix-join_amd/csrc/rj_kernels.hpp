@@ -113,6 +113,8 @@ void launch_join_bcast(const Launch& L, int key_words, int cw_build, int cw_prob
 //      and Table::to_columnar, src/build_table.cpp:456-594)
 void launch_gather(const Launch& L, const ColRef& src, const uint32_t* idx, uint64_t n,
                    const OutStream& dst, uint8_t* dst_valid);
+// test hook: keeps the stream busy for `ms` milliseconds (bounded; see RJ_DEBUG_SHARD_FAIL)
+void launch_debug_stall(const Launch& L, uint32_t ms);
 // wide carries (several payload columns travelling with the key): validity bits of up to three
 // columns as one word per row; the emitted records -> one dense array (+ validity bytes) per column
 void launch_pack_validity(const Launch& L, const uint8_t* v0, const uint8_t* v1, const uint8_t* v2, uint32_t n,

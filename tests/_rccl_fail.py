@@ -3,6 +3,9 @@
              (RJ_DEBUG_SHARD_FAIL: 1 preparing, 2 stage A, 3 receive buffers): the status word that
              travels with the counts makes it give up BEFORE the exchange, within seconds; a fresh
              context of the same process then joins correctly;
+  stall      the same job, but the rank's stage A takes "forever" (RJ_DEBUG_SHARD_FAIL=4: 7 s) with
+             RJ_EXCHANGE_TIMEOUT_MS=3000: the wait for the exchange expires, the communicator is
+             aborted, the call returns RJ_ERR_DEVICE, later calls fail at once, destroy returns;
   bringup    a context that claims to be rank 0 of a TWO-rank job whose rank 1 never starts:
              communicator bring-up is bounded by RJ_EXCHANGE_TIMEOUT_MS and fails instead of hanging.
 """
@@ -18,6 +21,11 @@ mode = sys.argv[1]
 if mode == "inject":
     os.environ["RJ_DEBUG_SHARD_FAIL"] = sys.argv[2]
     os.environ["RJ_DEBUG_SHARD_FAIL_RANK"] = "0"
+elif mode == "stall":
+    os.environ["RJ_DEBUG_SHARD_FAIL"] = "4"
+    os.environ["RJ_DEBUG_SHARD_FAIL_RANK"] = "0"
+    os.environ["RJ_EXCHANGE_TIMEOUT_MS"] = "3000"
+    os.environ["RJ_BRINGUP_TIMEOUT_MS"] = "60000"  # (a cold process takes seconds to load RCCL)
 else:
     os.environ["RJ_EXCHANGE_TIMEOUT_MS"] = "4000"
 
@@ -56,6 +64,28 @@ p.root = 2
 ctx = capi.Context(devices=[0], world_size=1, rank_base=0, comm_id=cid, exchange=capi.EXCHANGE_RCCL)
 tables = [[ctx.lane(0).upload(t) for t in p.inputs]]
 t0 = time.time()
+if mode == "stall":
+    try:
+        ctx.execute_sharded(p, tables)
+    except capi.RjError as e:
+        dt = time.time() - t0
+        assert e.code == 2 and "did not complete within 3000 ms" in e.message, e
+        assert 2.5 < dt < 15.0, dt  # (the error surfaces once this rank's own queued kernels have drained)
+        print(f"stalled exchange gave up after {dt:.1f} s: {e.message}", flush=True)
+    else:
+        raise SystemExit(f"the stalled exchange did not time out (the join returned after {time.time() - t0:.2f} s)")
+    try:  # the transport is marked failed: nothing else may be tried on it
+        ctx.execute_sharded(p, tables)
+    except capi.RjError as e:
+        assert "failed earlier" in e.message, e
+    else:
+        raise SystemExit("a failed transport accepted another join")
+    t1 = time.time()
+    for t in tables[0]:
+        t.release()
+    ctx.destroy()
+    print(f"destroyed {time.time() - t1:.1f} s later", flush=True)
+    sys.exit(0)
 try:
     ctx.execute_sharded(p, tables)
 except capi.RjError as e:

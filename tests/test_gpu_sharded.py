@@ -276,6 +276,14 @@ def test_rccl_local_failure_is_agreed_on_before_the_exchange(at):
     assert "surfaced after" in out and "joins correctly afterwards" in out
 
 
+def test_rccl_exchange_wait_is_bounded():
+    """A rank whose probe-side slices do not become ready (a 7 s stall) against a 3 s bound: the wait
+    for the exchange expires, the communicator is aborted, the call returns RJ_ERR_DEVICE, the
+    context refuses further joins and can still be destroyed."""
+    out = _child(["stall"], timeout=120)
+    assert "stalled exchange gave up after" in out and "destroyed" in out
+
+
 def test_rccl_bring_up_without_its_peers_is_bounded():
     """Rank 0 of a two-rank job whose rank 1 never starts: ncclCommInitRank would wait forever;
     the bring-up runs on a helper thread against RJ_EXCHANGE_TIMEOUT_MS and fails loudly."""
