@@ -73,6 +73,7 @@ int rj_context_create(rj_context** out, const rj_config* cfg) {
             c->prof.stream = c->stream;
             c->radix_bits_override = cfg ? cfg->radix_bits : 0;
             c->tune.from_env();
+            if (!c->radix_bits_override && c->tune.radix_bits > 0) c->radix_bits_override = c->tune.radix_bits;
             return c;
         };
         std::unique_ptr<rj_context> c = make_lane(devs[0], true);

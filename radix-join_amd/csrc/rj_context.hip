@@ -16,6 +16,7 @@ static int env_int(const char* name, int def) {
 }
 
 void Tuning::from_env() {
+    radix_bits = env_int("RJ_TUNE_RADIX_BITS", radix_bits);
     p1_bits = env_int("RJ_TUNE_P1_BITS", p1_bits);
     fine = env_int("RJ_TUNE_FINE", fine);
     pack = env_int("RJ_TUNE_PACK", pack);

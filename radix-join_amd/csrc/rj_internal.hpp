@@ -169,6 +169,7 @@ struct Result {
 // Tuning / diagnostic knobs, read from the environment ONCE when the context is created (the
 // plan walk is a hot host path: no getenv per join).
 struct Tuning {
+    int radix_bits = 0;   // RJ_TUNE_RADIX_BITS: total radix bits of every partitioned join (experiments; rj_config.radix_bits wins)
     int p1_bits = 0;      // RJ_TUNE_P1_BITS: radix bits of pass 1 in a two-pass plan (0 = even split)
     int fine = 1;         // RJ_TUNE_FINE: fine (two-digit) histogram for plans <= 2^PT_FINEBITS partitions
     int pack = 1;         // RJ_TUNE_PACK: 0 never, 1 always, 2 fine plans only: {key, carry} pairs

@@ -499,33 +499,51 @@ Result* execute_host_sharded(Context* g, const rj_plan* plan, const std::vector<
     if (largest < (uint64_t)nl * U) return nullptr;
     std::vector<std::vector<std::unique_ptr<Table>>> tabs((size_t)nl);
     std::vector<Table*>                              flat((size_t)nl * plan->n_inputs, nullptr);
-    std::vector<std::vector<rj_column>>              views;  // keep the column views alive
-    for (int l = 0; l < nl; ++l) {
-        Context* c = g->lane(l);
-        RJ_HIP(hipSetDevice(c->device));
+    std::vector<std::vector<rj_column>>              views((size_t)nl * plan->n_inputs);  // the shards' column views
+    std::vector<rj_input>                            shard((size_t)nl * plan->n_inputs, rj_input{});
+    for (int l = 0; l < nl; ++l)
         for (uint64_t i = 0; i < plan->n_inputs; ++i) {
+            if (!used[i]) continue;
             const rj_input& in = plan->inputs[i];
-            rj_input        view{};
-            if (used[i]) {
-                const uint64_t r0 = l == 0 ? 0 : (in.num_rows * (uint64_t)l / nl) / U * U;
-                const uint64_t r1 = l + 1 == nl ? in.num_rows : (in.num_rows * (uint64_t)(l + 1) / nl) / U * U;
-                views.emplace_back(in.cols, in.cols + in.n_cols);
-                std::vector<rj_column>& vc = views.back();
-                for (uint64_t k = 0; k < in.n_cols; ++k) {
-                    if (!col_used[i][k]) continue;
-                    const uint64_t rf = vc[k].type == RJ_INT32 ? ROWS32 : ROWS64;
-                    const uint64_t p0 = r0 / rf, p1 = (r1 + rf - 1) / rf;
-                    vc[k].pages = in.cols[k].pages + p0;
-                    vc[k].n_pages = p1 - p0;
-                }
-                view.num_rows = r1 - r0;
-                view.n_cols = in.n_cols;
-                view.cols = vc.data();
+            const uint64_t  r0 = l == 0 ? 0 : (in.num_rows * (uint64_t)l / nl) / U * U;
+            const uint64_t  r1 = l + 1 == nl ? in.num_rows : (in.num_rows * (uint64_t)(l + 1) / nl) / U * U;
+            std::vector<rj_column>& vc = views[(size_t)l * plan->n_inputs + i];
+            vc.assign(in.cols, in.cols + in.n_cols);
+            for (uint64_t k = 0; k < in.n_cols; ++k) {
+                if (!col_used[i][k]) continue;
+                const uint64_t rf = vc[k].type == RJ_INT32 ? ROWS32 : ROWS64;
+                const uint64_t p0 = r0 / rf, p1 = (r1 + rf - 1) / rf;
+                vc[k].pages = in.cols[k].pages + p0;
+                vc[k].n_pages = p1 - p0;
             }
-            tabs[l].emplace_back(table_upload(c, &view, used[i] ? &col_used[i] : nullptr, true));
-            flat[(size_t)l * plan->n_inputs + i] = tabs[l].back().get();
+            rj_input& view = shard[(size_t)l * plan->n_inputs + i];
+            view.num_rows = r1 - r0;
+            view.n_cols = in.n_cols;
+            view.cols = vc.data();
         }
+    // one uploading thread per device: every lane gathers pages into its own pinned staging and
+    // keeps its own PCIe link busy (the gathers take turns on the host workers, the copies overlap)
+    std::vector<std::exception_ptr> failed((size_t)nl);
+    auto upload_lane = [&](int l) {
+        try {
+            Context* c = g->lane(l);
+            RJ_HIP(hipSetDevice(c->device));
+            for (uint64_t i = 0; i < plan->n_inputs; ++i) {
+                tabs[l].emplace_back(table_upload(c, &shard[(size_t)l * plan->n_inputs + i], used[i] ? &col_used[i] : nullptr, true));
+                flat[(size_t)l * plan->n_inputs + i] = tabs[l].back().get();
+            }
+        } catch (...) {
+            failed[l] = std::current_exception();
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int l = 1; l < nl; ++l) th.emplace_back(upload_lane, l);
+        upload_lane(0);
+        for (std::thread& t : th) t.join();
     }
+    for (int l = 0; l < nl; ++l)
+        if (failed[l]) std::rethrow_exception(failed[l]);
     std::vector<Result*> parts((size_t)nl, nullptr);
     execute_sharded(g, plan, flat.data(), plan->n_inputs, 0, parts.data());
     // gather: rank 0's result takes the others' pages behind its own (pages of a Column need
