@@ -176,11 +176,17 @@ void rj_table_release(rj_context* ctx, rj_table* t);
  * page-fill rule of ColumnInserter (reference include/plan.h:151-335) — the resident table a
  * ScanNode then reads without any upload.  Runs BEFORE execute() in the harness and is untimed
  * there (tests/read_sql.cpp:1100-1107,1232-1236): SURVEY.md §8(f)#4.
- * Column types: INT32, INT64, VARCHAR (FP64 text is not parsed on the device:
- * RJ_ERR_UNSUPPORTED).  At most 2^32 - 16 bytes of text.
+ * Column types: INT32, INT64, FP64, VARCHAR.  FP64 fields become the double nearest to the decimal
+ * text, as std::from_chars does (build_table.cpp:57-64): the device decides all plain numbers
+ * (sign, digits, point, exponent) by the Eisel-Lemire algorithm; "inf" / "nan", fields with
+ * characters behind the number and the rare text whose rounding 128 bits cannot settle are
+ * handed to the host's std::from_chars.  At most 2^32 - 16 bytes of text.
  * Errors (RJ_ERR_DATA) as the reference raises them: "CSV parse error" (a record with another
  * number of fields than n_cols, a quote left open: csv_parser.h:9-14, build_table.cpp:236,243),
- * "parse integer error" (:42-44).
+ * "parse integer error" (:42-44), "parse float error" (:59-61: not a number, or a value no
+ * double represents — overflow, or non-zero text that rounds to zero).  A text with several
+ * errors raises the structural one first, then the integer, then the float one (the reference
+ * raises whichever comes first in the text).
  *
  * filter: a postfix program over the table's columns (reference include/statement.h,
  * src/statement.cpp:46-135,186-201) — comparison and IS [NOT] NULL leaves push a row bitmap,
@@ -192,6 +198,8 @@ void rj_table_release(rj_context* ctx, rj_table* t);
 typedef enum rj_filter_opcode {
     RJ_F_EQ = 0, RJ_F_NEQ = 1, RJ_F_LT = 2, RJ_F_GT = 3, RJ_F_LEQ = 4, RJ_F_GEQ = 5, /* column <op> literal.  INT32 / INT64
                                         columns: ivalue (an INT32 column compares with (int32_t)ivalue: statement.cpp:55);
+                                        FP64 columns: ivalue holds the BITS of the double literal, compared as doubles
+                                        are (statement.cpp:91-107: a NaN equals nothing);
                                         VARCHAR columns: the ivalue bytes at `bytes`, compared as std::string does
                                         (unsigned bytes, then length: statement.cpp:117-126)                    */
     RJ_F_IS_NULL = 6, RJ_F_IS_NOT_NULL = 7,                   /* any column                                   */
@@ -216,6 +224,10 @@ int rj_table_from_csv(rj_context* ctx, const char* text, uint64_t n_bytes, uint6
                       const int32_t* col_type, const rj_filter_op* filter, uint64_t n_filter_ops,
                       rj_table** out);
 /* A resident table's shape and pages (tests compare them with the reference's fill rule). */
+/* The FP64 field parser of rj_table_from_csv on ONE field, run on the host (no device needed;
+ * tests): 0 = *bits holds the double, 1 = out of range ("parse float error"), 2 = left to
+ * std::from_chars.                                                                             */
+int rj_debug_parse_fp64(const char* field, uint64_t n, uint64_t* bits);
 uint64_t rj_table_num_rows(const rj_table* t);
 uint64_t rj_table_col_pages(const rj_table* t, uint64_t col);
 int      rj_table_copy_pages(rj_context* ctx, const rj_table* t, uint64_t col, void* const* dst, uint64_t n_dst);

@@ -20,6 +20,7 @@
  * `new Page` undefined: tests compare the defined bytes.
  */
 #include <errno.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -107,6 +108,81 @@ static int parse_int(const char* b, size_t len, int bits, int64_t* out) {
     return 0;
 }
 
+/* std::from_chars(first, last, double&) with chars_format::general (build_table.cpp:57-64), as the
+ * C++ standard words it: no leading white space, no '+', the LONGEST prefix that is a decimal
+ * floating number, "inf" / "infinity" / "nan" / "nan(n-char-seq)" in any case; the result is the
+ * nearest double (glibc's strtod on exactly that prefix is correctly rounded too); a value no
+ * double represents — overflow, or a non-zero text that rounds to zero — is result_out_of_range,
+ * which TableParser turns into "parse float error" like a missing number.  Subnormal results are
+ * representable (libstdc++ 11 and later agree). */
+static int lower(int ch) { return ch >= 'A' && ch <= 'Z' ? ch + 32 : ch; }
+static int parse_double(const char* b, size_t len, double* out) {
+    size_t p = 0, start;
+    int    neg = 0, special = 0, nonzero = 0, digits = 0;
+    if (p < len && b[p] == '-') {
+        neg = 1;
+        ++p;
+    }
+    (void)neg;
+    start = p;
+    if (len - p >= 3 && lower(b[p]) == 'i' && lower(b[p + 1]) == 'n' && lower(b[p + 2]) == 'f') {
+        special = 1;
+        p += 3;
+        if (len - p >= 5 && lower(b[p]) == 'i' && lower(b[p + 1]) == 'n' && lower(b[p + 2]) == 'i' && lower(b[p + 3]) == 't' &&
+            lower(b[p + 4]) == 'y')
+            p += 5;
+    } else if (len - p >= 3 && lower(b[p]) == 'n' && lower(b[p + 1]) == 'a' && lower(b[p + 2]) == 'n') {
+        /* the n-char-seq is consumed but carries nothing: libstdc++ returns the default quiet NaN
+         * (observed with GCC 11.4: "nan(12)" -> 0x7ff8000000000000), glibc's strtod would make a payload of it */
+        *out = neg ? -NAN : NAN;
+        return 0;
+        if (p < len && b[p] == '(') {
+            size_t q = p + 1;
+            while (q < len && ((b[q] >= '0' && b[q] <= '9') || (lower(b[q]) >= 'a' && lower(b[q]) <= 'z') || b[q] == '_')) ++q;
+            if (q < len && b[q] == ')') p = q + 1;
+        }
+    } else {
+        while (p < len && b[p] >= '0' && b[p] <= '9') {
+            nonzero |= b[p] != '0';
+            ++digits;
+            ++p;
+        }
+        if (p < len && b[p] == '.') {
+            size_t q = p + 1;
+            int    fd = 0;
+            while (q < len && b[q] >= '0' && b[q] <= '9') {
+                nonzero |= b[q] != '0';
+                ++fd;
+                ++q;
+            }
+            if (digits || fd) p = q; /* "5." and ".5" are numbers, "." is not */
+            digits += fd;
+        }
+        if (!digits) return -1;
+        if (p < len && (b[p] == 'e' || b[p] == 'E')) { /* an exponent only with digits behind it */
+            size_t q = p + 1;
+            if (q < len && (b[q] == '+' || b[q] == '-')) ++q;
+            if (q < len && b[q] >= '0' && b[q] <= '9') {
+                while (q < len && b[q] >= '0' && b[q] <= '9') ++q;
+                p = q;
+            }
+        }
+    }
+    if (p == start) return -1;
+    {
+        char*  tmp = (char*)malloc(p + 1);
+        double v;
+        if (!tmp) return -1;
+        memcpy(tmp, b, p);
+        tmp[p] = 0;
+        v = strtod(tmp, NULL);
+        free(tmp);
+        if (!special && (v == HUGE_VAL || v == -HUGE_VAL || (v == 0 && nonzero))) return -1;
+        *out = v;
+    }
+    return 0;
+}
+
 /* TableParser::on_field (build_table.cpp:31-76) */
 static int on_field(icol* cols, uint64_t n_cols, size_t col_idx, const char* b, size_t len, char* err, size_t cap) {
     if (col_idx >= n_cols) return failmsg(err, cap, "CSV parse error");
@@ -126,20 +202,9 @@ static int on_field(icol* cols, uint64_t n_cols, size_t col_idx, const char* b, 
         case RJ_INT64:
             if (parse_int(b, len, c->type == RJ_INT32 ? 32 : 64, &c->i[c->n])) return failmsg(err, cap, "parse integer error");
             break;
-        case RJ_FP64: {
-            /* std::from_chars(double) does not skip white space and takes no '+': pre-check, then strtod */
-            if (!((b[0] >= '0' && b[0] <= '9') || b[0] == '-' || b[0] == '.' || b[0] == 'i' || b[0] == 'n' || b[0] == 'I' || b[0] == 'N'))
-                return failmsg(err, cap, "parse float error");
-            char  tmp[512];
-            size_t l = len < sizeof tmp - 1 ? len : sizeof tmp - 1;
-            memcpy(tmp, b, l);
-            tmp[l] = 0;
-            char* endp = NULL;
-            errno = 0;
-            c->f[c->n] = strtod(tmp, &endp);
-            if (endp == tmp || errno == ERANGE) return failmsg(err, cap, "parse float error");
+        case RJ_FP64:
+            if (parse_double(b, len, &c->f[c->n])) return failmsg(err, cap, "parse float error");
             break;
-        }
         default: /* VARCHAR */
             if (c->hn + len > c->hcap) {
                 size_t nc = c->hcap ? c->hcap * 2 : 4096;
@@ -346,6 +411,20 @@ static int eval_filter(const rj_filter_op* ops, uint64_t n_ops, const icol* cols
                     case RJ_F_GT: cmp = d > 0; break;
                     case RJ_F_LEQ: cmp = d <= 0; break;
                     case RJ_F_GEQ: cmp = d >= 0; break;
+                    default: return -1;
+                    }
+                    v = nn & cmp;
+                } else if (c->type == RJ_FP64) { /* statement.cpp:91-107: the literal is a double */
+                    double x = c->f[r], y;
+                    int    cmp = 0;
+                    memcpy(&y, &o->ivalue, 8);
+                    switch (o->op) {
+                    case RJ_F_EQ: cmp = x == y; break;
+                    case RJ_F_NEQ: cmp = x != y; break;
+                    case RJ_F_LT: cmp = x < y; break;
+                    case RJ_F_GT: cmp = x > y; break;
+                    case RJ_F_LEQ: cmp = x <= y; break;
+                    case RJ_F_GEQ: cmp = x >= y; break;
                     default: return -1;
                     }
                     v = nn & cmp;

@@ -63,7 +63,9 @@ int rjo_encode_varchar(const uint64_t* offsets, const char* heap, const uint8_t*
  * (src/csv_parser.cpp:3-175, escape '\\', separator ','), TableParser::on_field (:31-76: empty field
  * = NULL, std::from_chars for integers), the filter as bitmap arithmetic (src/statement.cpp:8-135,
  * 186-201; include/inner_column.h:170-324) and from_inner_to_column with ColumnInserter's
- * page-fill rule (:94-119, include/plan.h:151-335).  FP64 columns are parsed with strtod.
+ * page-fill rule (:94-119, include/plan.h:151-335).  FP64 fields: std::from_chars(double) restated
+ * (longest-prefix grammar, nearest double via strtod, out-of-range = error; FP64 comparison leaves
+ * carry the literal's bits in ivalue).
  * Returns 0, or -1 with err set to the reference's message.                                     */
 int rjo_from_csv(const char* text, uint64_t n_bytes, uint64_t n_cols, const int32_t* col_type,
                  const rj_filter_op* filter, uint64_t n_filter_ops, rjo_result** out, char* err, size_t errcap);

@@ -175,6 +175,11 @@ int rj_table_from_csv(rj_context* ctx, const char* text, uint64_t n_bytes, uint6
     });
 }
 
+int rj_debug_parse_fp64(const char* field, uint64_t n, uint64_t* bits) {
+    if (!bits || (n && !field)) return RJ_ERR_ARG;
+    return rj::parse_fp64_host(field, n, bits);
+}
+
 uint64_t rj_table_num_rows(const rj_table* t) { return t ? t->num_rows : 0; }
 uint64_t rj_table_col_pages(const rj_table* t, uint64_t col) { return table_col_pages(t, col); }
 

@@ -4,7 +4,7 @@
 // Replaces, for the harness's CSV dialect (escape '\\', separator ',', no header, no trailing
 // comma: reference src/build_table.cpp:231):
 //   CSVParser::execute / finish     src/csv_parser.cpp:3-175      k_csv_trans .. k_csv_emit
-//   TableParser::on_field           src/build_table.cpp:31-76     k_csv_ints, k_csv_strlen
+//   TableParser::on_field           src/build_table.cpp:31-76     k_csv_ints, k_csv_f64, k_csv_strlen
 //   Comparison / LogicalOperation   src/statement.cpp:8-135,186-201 (over include/inner_column.h:
 //                                   170-324, :372-562 for strings; LIKE: statement.h:118-161) k_ing_filter
 //   from_inner_to_column +          src/build_table.cpp:94-119,
@@ -29,12 +29,25 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <atomic>
+#include <charconv>
+#include <cstring>
+#include <string>
 
+#include "rj_fp64.hpp"
 #include "rj_internal.hpp"
 
 namespace rj {
 
 namespace {
+
+// 128-bit powers of five for the FP64 parser (rj_fp64.hpp), on the device and on the host
+__device__ const uint64_t d_pow5[] = {
+#include "rj_pow5_table.inc"
+};
+const uint64_t h_pow5[] = {
+#include "rj_pow5_table.inc"
+};
 
 constexpr uint32_t SEG = 256;   // bytes a thread walks in the structural passes
 constexpr uint32_t SUP = 256;   // segments per super-segment
@@ -303,6 +316,43 @@ __global__ __launch_bounds__(256) void k_csv_ints(const uint8_t* t, const uint32
     valid[r] = any ? 1 : 0;
 }
 
+// FP64 columns: std::from_chars(double) (build_table.cpp:57-64) — the nearest double of the
+// decimal text (rj_fp64.hpp).  Fields outside the plain number grammar ("inf", "nan", a number
+// followed by other characters ...) and the few whose rounding the 128-bit product cannot settle
+// are listed in `hard` for the host's std::from_chars; info[5] counts "parse float error"s,
+// info[6] the listed rows.
+__global__ __launch_bounds__(256) void k_csv_f64(const uint8_t* t, const uint32_t* fend, uint32_t n_cols, uint32_t col,
+                                                 uint32_t n_rows, uint64_t* values, uint8_t* valid, uint32_t* info, uint32_t* hard) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const Field f = field_of(t, fend, n_cols, r, col);
+    FieldChars  probe{t, f.beg, f.end, 0};
+    uint8_t     c;
+    const bool  any = probe.next(c);
+    uint64_t    bits = 0;
+    if (any) {
+        FieldChars it{t, f.beg, f.end, 0};
+        const int  st = parse_fp64_field(it, d_pow5, &bits);
+        if (st == FP64_RANGE) atomicAdd(&info[5], 1u);
+        if (st == FP64_UNDECIDED) hard[atomicAdd(&info[6], 1u)] = r;
+        if (st != FP64_PARSED) bits = 0;
+    }
+    values[r] = bits;
+    valid[r] = any ? 1 : 0;
+}
+// where the listed rows' fields lie in the text (for the host), and their values coming back
+__global__ __launch_bounds__(256) void k_csv_field_bounds(const uint8_t* t, const uint32_t* fend, uint32_t n_cols, uint32_t col,
+                                                          const uint32_t* rows, uint32_t n, uint2* bounds) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Field f = field_of(t, fend, n_cols, rows[i], col);
+    bounds[i] = make_uint2(f.beg, f.end);
+}
+__global__ __launch_bounds__(256) void k_csv_patch64(const uint32_t* rows, const uint64_t* vals, uint32_t n, uint64_t* values) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) values[rows[i]] = vals[i];
+}
+
 // VARCHAR columns: decoded length of every row's string, NULL_LEN for an empty field
 __global__ __launch_bounds__(256) void k_csv_strlen(const uint8_t* t, const uint32_t* fend, uint32_t n_cols, uint32_t col,
                                                     uint32_t n_rows, uint32_t* len) {
@@ -386,7 +436,7 @@ struct DevFilterOp {
     const uint8_t* bytes;  // device copy of the host bitmap / the string literal / the LIKE tokens (u32 each)
 };
 struct DevCol {
-    const uint8_t*  values;  // INT32 / INT64
+    const uint8_t*  values;  // INT32 / INT64 / FP64
     const uint8_t*  valid;   // fixed-width
     const uint32_t* len;     // VARCHAR (NULL_LEN = NULL)
     int32_t         type, pad;
@@ -466,7 +516,19 @@ __global__ __launch_bounds__(256) void k_ing_filter(const FilterProg* pp, uint32
                     v = !nn;
                 else if (o.op == RJ_F_IS_NOT_NULL)
                     v = nn;
-                else {
+                else if (c.type == RJ_FP64) {  // IEEE comparisons against a double literal (statement.cpp:91-107)
+                    const double x = reinterpret_cast<const double*>(c.values)[r], y = __longlong_as_double(o.ivalue);
+                    bool         cmp = false;
+                    switch (o.op) {
+                    case RJ_F_EQ: cmp = x == y; break;
+                    case RJ_F_NEQ: cmp = x != y; break;
+                    case RJ_F_LT: cmp = x < y; break;
+                    case RJ_F_GT: cmp = x > y; break;
+                    case RJ_F_LEQ: cmp = x <= y; break;
+                    default: cmp = x >= y; break;
+                    }
+                    v = nn && cmp;
+                } else {
                     const int64_t x = c.type == RJ_INT32 ? (int64_t)reinterpret_cast<const int32_t*>(c.values)[r]
                                                          : reinterpret_cast<const int64_t*>(c.values)[r];
                     const int64_t y = c.type == RJ_INT32 ? (int64_t)(int32_t)o.ivalue : o.ivalue;  // statement.cpp:55
@@ -798,7 +860,6 @@ Table* table_from_csv(Context* ctx, const char* text, uint64_t n_bytes, uint64_t
     if (n_filter_ops > (uint64_t)MAX_FILTER_OPS) throw_fmt(RJ_ERR_UNSUPPORTED, "from_csv: filter longer than %d operations", MAX_FILTER_OPS);
     if (n_bytes > 0xffffffe0ull) throw_fmt(RJ_ERR_UNSUPPORTED, "from_csv: more than 2^32 bytes of text");
     for (uint64_t c = 0; c < n_cols; ++c) {
-        if (col_type[c] == RJ_FP64) throw_fmt(RJ_ERR_UNSUPPORTED, "from_csv: FP64 text is not parsed on the device");
         if (col_type[c] < RJ_INT32 || col_type[c] > RJ_VARCHAR) throw_fmt(RJ_ERR_ARG, "from_csv: bad column type");
     }
     {  // the filter must be a well-formed postfix program over columns it may touch
@@ -914,7 +975,55 @@ Table* table_from_csv(Context* ctx, const char* text, uint64_t n_bytes, uint64_t
             const int W = col_type[c] == RJ_INT32 ? 4 : 8;
             ty.values = ctx->buf((size_t)n_rows * W);
             ty.valid = ctx->buf(n_rows);
-            if (W == 4)
+            if (col_type[c] == RJ_FP64) {
+                BufP hard = ctx->buf((size_t)n_rows * 4);
+                RJ_HIP(hipMemsetAsync(dinfo + 6, 0, 4, ctx->stream));
+                RJ_ILAUNCH(L, "csv_fields", k_csv_f64, rgrid, 256, t, fend->as<uint32_t>(), (uint32_t)n_cols, (uint32_t)c, n_rows,
+                           ty.values->as<uint64_t>(), ty.valid->as<uint8_t>(), dinfo, hard->as<uint32_t>());
+                const uint32_t n_hard = read_u32(ctx, dinfo + 6);
+                if (n_hard) {
+                    // the host's std::from_chars takes the fields the device left undecided
+                    BufP bounds = ctx->buf((size_t)n_hard * 8), vals = ctx->buf((size_t)n_hard * 8);
+                    RJ_ILAUNCH(L, "csv_fields", k_csv_field_bounds, (n_hard + 255) / 256, 256, t, fend->as<uint32_t>(), (uint32_t)n_cols,
+                               (uint32_t)c, hard->as<uint32_t>(), n_hard, bounds->as<uint2>());
+                    std::vector<uint2>    hb(n_hard);
+                    std::vector<uint64_t> hv(n_hard, 0);
+                    RJ_HIP(hipMemcpyAsync(hb.data(), bounds->p, (size_t)n_hard * 8, hipMemcpyDeviceToHost, ctx->stream));
+                    ctx->sync();
+                    std::atomic<uint32_t> bad{0};
+                    parallel_for(n_hard, 1024, [&](size_t b0, size_t e0) {
+                        std::string fld;
+                        for (size_t i = b0; i < e0; ++i) {
+                            // the characters on_field sees: quotes dropped, escapes applied (FieldChars)
+                            fld.clear();
+                            const uint32_t end = std::min<uint32_t>(hb[i].y, (uint32_t)n_bytes);
+                            uint32_t       st = 0;
+                            for (uint32_t p = hb[i].x; p < end;) {
+                                const char x = text[p++];
+                                if (st == 0) {
+                                    if (x == '"') st = 1;
+                                    else fld.push_back(x);
+                                } else if (x == '"') {
+                                    st = 0;
+                                } else if (x == '\\' && p < end && (text[p] == '"' || text[p] == '\\')) {
+                                    fld.push_back(text[p++]);
+                                } else {
+                                    fld.push_back(x);
+                                }
+                            }
+                            double     v = 0;
+                            const auto res = std::from_chars(fld.data(), fld.data() + fld.size(), v);
+                            if (res.ec != std::errc()) ++bad;
+                            memcpy(&hv[i], &v, 8);
+                        }
+                    });
+                    if (bad.load()) throw_fmt(RJ_ERR_DATA, "parse float error");
+                    RJ_HIP(hipMemcpyAsync(vals->p, hv.data(), (size_t)n_hard * 8, hipMemcpyHostToDevice, ctx->stream));
+                    RJ_ILAUNCH(L, "csv_fields", k_csv_patch64, (n_hard + 255) / 256, 256, hard->as<uint32_t>(), vals->as<uint64_t>(), n_hard,
+                               ty.values->as<uint64_t>());
+                    ctx->sync();  // (hv is pageable and local)
+                }
+            } else if (W == 4)
                 RJ_ILAUNCH(L, "csv_fields", (k_csv_ints<4>), rgrid, 256, t, fend->as<uint32_t>(), (uint32_t)n_cols, (uint32_t)c,
                            n_rows, ty.values->as<uint8_t>(), ty.valid->as<uint8_t>(), dinfo);
             else
@@ -925,6 +1034,7 @@ Table* table_from_csv(Context* ctx, const char* text, uint64_t n_bytes, uint64_t
                                ty.len ? ty.len->as<uint32_t>() : nullptr, col_type[c], 0};
     }
     if (read_u32(ctx, dinfo + 4) != 0) throw_fmt(RJ_ERR_DATA, "parse integer error");
+    if (read_u32(ctx, dinfo + 5) != 0) throw_fmt(RJ_ERR_DATA, "parse float error");
     // ---- filter -> selection -> output row of every selected row
     std::vector<BufP> bitmaps;
     prog->n_ops = (uint32_t)n_filter_ops;
@@ -1064,6 +1174,19 @@ Table* table_from_csv(Context* ctx, const char* text, uint64_t n_bytes, uint64_t
         tab->cols[c].owned = page_bufs[c];
     }
     return tab.release();
+}
+
+// the device's FP64 field parser, compiled for the host (rj_debug_parse_fp64: CPU tests)
+int parse_fp64_host(const char* s, uint64_t n, uint64_t* bits) {
+    struct It {
+        const char *p, *e;
+        bool        next(uint8_t& c) {
+            if (p == e) return false;
+            c = (uint8_t)*p++;
+            return true;
+        }
+    } it{s, s + n};
+    return parse_fp64_field(it, h_pow5, bits);
 }
 
 uint64_t table_col_pages(const Table* t, uint64_t col) {

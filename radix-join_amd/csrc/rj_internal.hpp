@@ -312,6 +312,7 @@ Result* execute_host_sharded(Context* group, const rj_plan* plan, const std::vec
 // rj_ingest.hip — Table::from_csv on the device
 Table*   table_from_csv(Context* ctx, const char* text, uint64_t n_bytes, uint64_t n_cols, const int32_t* col_type,
                         const rj_filter_op* filter, uint64_t n_filter_ops);
+int parse_fp64_host(const char* s, uint64_t n, uint64_t* bits);  // rj_fp64.hpp on the host: 0 parsed, 1 out of range, 2 undecided
 uint64_t table_col_pages(const Table* t, uint64_t col);
 void     table_copy_pages(Context* ctx, const Table* t, uint64_t col, void* const* dst, uint64_t n_dst);
 

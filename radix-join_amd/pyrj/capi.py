@@ -76,6 +76,8 @@ def filter_to_c(prog):
             lit = np.frombuffer(bytes(term[2]) or b"\0", dtype=np.uint8).copy()
             keep.append(lit)
             arr[k].column, arr[k].ivalue, arr[k].bytes = int(term[1]), len(term[2]), lit.ctypes.data
+        elif op <= 5 and isinstance(term[2], float):  # FP64 column: the literal's bits
+            arr[k].column, arr[k].ivalue = int(term[1]), int(np.array([term[2]], dtype=np.float64).view(np.int64)[0])
         elif op <= 5:
             arr[k].column, arr[k].ivalue = int(term[1]), int(term[2])
         elif op in (6, 7):
@@ -119,6 +121,7 @@ EXPORTS = [
     "rj_table_adopt_device",
     "rj_table_release",
     "rj_table_from_csv",
+    "rj_debug_parse_fp64",
     "rj_table_num_rows",
     "rj_table_col_pages",
     "rj_table_copy_pages",
@@ -560,6 +563,17 @@ def exchange_plan(world: int, subs: int, rank: int, counts) -> dict:
         raise RjError(rc, (L.rj_last_error(None) or b"").decode())
     out["n_recv"] = int(n_recv.value)
     return out
+
+
+def parse_fp64(field: bytes):
+    """rj_debug_parse_fp64: the ingest's FP64 field parser on the host.  -> (status, bits): 0 parsed,
+    1 out of range, 2 left to std::from_chars."""
+    L = load()
+    L.rj_debug_parse_fp64.restype = C.c_int
+    L.rj_debug_parse_fp64.argtypes = [C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64)]
+    bits = C.c_uint64(0)
+    st = L.rj_debug_parse_fp64(field, len(field), C.byref(bits))
+    return int(st), int(bits.value)
 
 
 def make_comm_id() -> bytes:

@@ -5,8 +5,68 @@ and escapes at random wherever the dialect allows it, and an independent row-lev
 filter programs."""
 import numpy as np
 
-INT32, INT64, VARCHAR = 0, 1, 3
+INT32, INT64, FP64, VARCHAR = 0, 1, 2, 3
 _SPECIAL = b',"\n\r'
+
+
+class FText(float):
+    """an FP64 cell: the double a correctly rounding reader makes of `text` (Python's float() is
+    one), together with that text — the CSV writer emits it as it stands"""
+
+    def __new__(cls, text: str):
+        self = super().__new__(cls, text)
+        self.text = text
+        return self
+
+
+def random_fp64_text(rng) -> str:
+    """_random_fp64_text() without the texts whose value no double represents (overflow, or non-zero
+    text that rounds to zero): those are errors in the reference and tested on their own"""
+    s = _random_fp64_text(rng)
+    v = float(s)
+    sig = s.lower().split("e")[0]
+    if v in (float("inf"), float("-inf")) or (v == 0 and any(ch in "123456789" for ch in sig)):
+        return "0.25"
+    return s
+
+
+def _random_fp64_text(rng) -> str:
+    """decimal text of the plain grammar std::from_chars(double) reads: sign, digits, point,
+    exponent; short and long significands, values across the whole exponent range (subnormals
+    included), texts that sit next to a rounding boundary"""
+    k = int(rng.integers(0, 9))
+    bits = int(rng.integers(0, 2**63, dtype=np.uint64)) | (int(rng.integers(0, 2)) << 63)
+    d = float(np.array([bits], dtype=np.uint64).view(np.float64)[0])
+    if not np.isfinite(d):
+        d = 1.5
+    if k == 0:
+        return repr(d)  # shortest text that reads back as d
+    if k == 1:
+        return "%.*e" % (int(rng.integers(0, 24)), d)
+    if k == 2:
+        return "%d.%0*d" % (int(rng.integers(-10**6, 10**6)), int(rng.integers(1, 10)), int(rng.integers(0, 10**9)))
+    if k == 3:
+        digs = "".join(str(int(x)) for x in rng.integers(0, 10, int(rng.integers(1, 32))))
+        at = int(rng.integers(0, len(digs) + 1))
+        s = digs[:at] + ("." if rng.random() < 0.6 else "") + digs[at:]
+        if rng.random() < 0.5:
+            s += "eE"[int(rng.integers(0, 2))] + ["", "+", "-"][int(rng.integers(0, 3))] + str(int(rng.integers(0, 330)))
+        return ("-" if rng.random() < 0.3 else "") + s
+    if k == 4:  # half-way between two doubles, cut off after 17..40 digits
+        from decimal import Decimal, getcontext
+
+        getcontext().prec = 60
+        a = abs(d) if abs(d) < 1e300 else 1.0
+        mid = (Decimal(a) + Decimal(float(np.nextafter(a, np.inf)))) / 2
+        return ("%.*e" % (int(rng.integers(16, 40)), mid)) if mid else "0"
+    if k == 5:  # subnormals
+        sub = float(np.array([int(rng.integers(1, 2**52))], dtype=np.uint64).view(np.float64)[0])
+        return "%.*e" % (int(rng.integers(0, 20)), sub)
+    if k == 6:
+        return str(int(rng.integers(-(2**63), 2**63 - 1)))
+    if k == 7:
+        return ["0", "-0", "0.0", "-0.0e5", ".5", "5.", "-.5", "1E5", "1e+5", "4.9e-324", "1.7976931348623157e308"][int(rng.integers(0, 11))]
+    return "%.3f" % (float(rng.integers(-10**6, 10**6)) / 1000)
 
 
 def random_rows(rng, n, types, null_p=0.1, long_p=0.0):
@@ -21,6 +81,8 @@ def random_rows(rng, n, types, null_p=0.1, long_p=0.0):
         elif ty == INT64:
             v = rng.integers(-(2**63), 2**63 - 1, n)
             cols.append([None if nulls[i] else int(v[i]) for i in range(n)])
+        elif ty == FP64:
+            cols.append([None if nulls[i] else FText(random_fp64_text(rng)) for i in range(n)])
         else:
             alphabet = np.frombuffer(b"abcdefghij KLMNOP0123456789,\"\\\n\r;:'-_", dtype=np.uint8)
             lens = rng.integers(1, 40, n)
@@ -41,6 +103,9 @@ def random_rows(rng, n, types, null_p=0.1, long_p=0.0):
 def field_text(rng, v):
     if v is None:
         return b"" if rng.random() < 0.8 else b'""'  # an empty field is NULL, quoted or not
+    if isinstance(v, FText):
+        s = v.text.encode()
+        return b'"' + s + b'"' if rng.random() < 0.1 else s
     if isinstance(v, (int, np.integer)):
         s = str(int(v)).encode()
         return b'"' + s + b'"' if rng.random() < 0.1 else s
@@ -129,6 +194,12 @@ def random_filter(rng, rows, types, depth=3):
             leaves.append(lambda c=c: (["EQ", "NEQ", "LT", "GT", "LEQ", "GEQ"][int(rng.integers(0, 6))], c, int(rng.integers(-100, 2100))))
         elif ty == INT64:
             leaves.append(lambda c=c: (["LT", "GT", "LEQ", "GEQ"][int(rng.integers(0, 4))], c, int(rng.integers(-(2**62), 2**62))))
+        elif ty == FP64:
+            def fcmp(c=c):
+                pool = [float(row[c]) for row in rows[:50] if row[c] is not None] or [0.0]
+                lit = pool[int(rng.integers(0, len(pool)))] if rng.random() < 0.6 else float(rng.normal()) * 10.0 ** int(rng.integers(-5, 6))
+                return (["EQ", "NEQ", "LT", "GT", "LEQ", "GEQ"][int(rng.integers(0, 6))], c, float(lit))
+            leaves.append(fcmp)
         else:
             # string comparisons run on the device (std::string order: unsigned bytes, then length)
             def strcmp(c=c):

@@ -14,7 +14,7 @@ from pyrj import capi
 from pyrj import plan as pl
 
 pytestmark = pytest.mark.gpu
-I32, I64, VC = g.INT32, g.INT64, g.VARCHAR
+I32, I64, F64, VC = g.INT32, g.INT64, g.FP64, g.VARCHAR
 
 
 @pytest.fixture(scope="module")
@@ -48,10 +48,10 @@ def test_dialect_by_hand(ctx):
     assert want.num_rows == 7
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(21))
 def test_random_tables_and_filters(ctx, seed):
     rng = np.random.default_rng(7000 + seed)
-    types = [[I32, VC, I64], [VC, I32], [I32, I32, VC, VC], [I64, I32], [I32]][seed % 5]
+    types = [[I32, VC, I64], [VC, I32], [I32, I32, VC, VC], [I64, I32], [I32], [F64, I32], [VC, F64, F64, I64]][seed % 7]
     n = int(rng.integers(1, 60000)) if seed % 4 else int(rng.integers(1, 700))
     rows = g.random_rows(rng, n, types, null_p=[0.0, 0.1, 0.5, 0.95][seed % 4], long_p=0.001 if seed % 3 == 0 else 0.0)
     if len(types) == 1:
@@ -94,6 +94,13 @@ def test_long_strings_and_all_null_pages(ctx):
     (b"1,-\n", [I32, I32], "parse integer error"),
     (b"1,2147483648\n", [I32, I32], "parse integer error"),
     (b"1,9223372036854775808\n", [I32, I64], "parse integer error"),
+    (b"1,x\n", [I32, F64], "parse float error"),
+    (b"1,+5\n", [I32, F64], "parse float error"),
+    (b"1,.\n2,3\n", [I32, F64], "parse float error"),
+    (b"1,1e999\n", [I32, F64], "parse float error"),
+    (b"1,-1e-999\n", [I32, F64], "parse float error"),
+    (b"1,2.4703282292062327e-324\n", [I32, F64], "parse float error"),
+    (b"1," + b"9" * 400 + b"\n", [I32, F64], "parse float error"),
 ])
 def test_errors_as_the_reference_raises_them(ctx, text, types, msg):
     with pytest.raises(capi.RjError) as e:
@@ -108,14 +115,29 @@ def test_prefix_parse_literal_truncation_and_unsupported(ctx):
     same_pages(ctx, b"12abc,-2147483648\n7,2147483647\n", [I32, I32])
     same_pages(ctx, b"12,1\n7,2\n", [I32, I32], [("EQ", 0, 2**32 + 7)])
     same_pages(ctx, b"", [I32, VC])
-    with pytest.raises(capi.RjError) as e:
-        ctx.from_csv(b"1.5\n", [pl.FP64])
-    assert e.value.code == 5  # FP64 text is not parsed on the device
     same_pages(ctx, b'abc\n"ab"\n\nabd\n"a,b"\nab\\\n', [VC], [("GEQ", 0, b"ab"), ("LT", 0, b"abd"), ("AND",)])
     same_pages(ctx, b'abc\nab\n\n', [VC], [("EQ", 0, b"")])  # nothing equals the empty string: an empty field is NULL
     with pytest.raises(capi.RjError) as e:
         ctx.from_csv(b"1\n", [I32], [("AND",)])
     assert e.value.code == 1
+
+
+def test_fp64_fields(ctx):
+    """std::from_chars(double) (reference src/build_table.cpp:57-64): plain numbers are decided on the
+    device, everything else it accepts — the longest numeric prefix, inf / nan in any case, quoted
+    fields — by the host's std::from_chars; pages byte for byte the oracle's (NaN payloads included)."""
+    text = (b'1.5,1\n-0,2\n"2.5e3",3\n,4\n.5,5\n5.,6\n-.5e-3,7\n12abc,8\n1e,9\n1e+,10\n0x10,11\ninf,12\n-INF,13\n'
+            b'Infinity,14\nnan,15\n-nan,16\nNaN(12),17\n1.5.2,18\n9007199254740993,19\n4.9e-324,20\n1.7976931348623157e308,21\n'
+            b'0.000000000000000000000000000000000001,22\n123456789012345678901234567890,23\n'
+            b'1.00000000000000011102230246251565404236316680908203125,24\n"1.0\\"",25\n')
+    want = same_pages(ctx, text, [F64, I32])
+    assert want.num_rows == 25
+    same_pages(ctx, text, [F64, I32], [("GT", 0, 1.0), ("IS_NULL", 0), ("OR",)])
+    same_pages(ctx, text, [F64, I32], [("NEQ", 0, float("nan"))])   # a NaN differs from everything, itself included
+    same_pages(ctx, text, [F64, I32], [("EQ", 0, 0.0)])            # -0 equals 0
+    rng = np.random.default_rng(77)
+    rows = g.random_rows(rng, 300_000, [F64, F64], null_p=0.3)     # NULL-bearing 8-byte pages: the +4 quirk of the inserter
+    same_pages(ctx, g.to_csv(rng, rows), [F64, F64])
 
 
 def test_like_on_the_device(ctx):

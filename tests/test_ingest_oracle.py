@@ -18,7 +18,7 @@ import _oracle
 from pyrj import pages as pg
 from pyrj import plan as pl
 
-I32, I64, VC = g.INT32, g.INT64, g.VARCHAR
+I32, I64, F64, VC = g.INT32, g.INT64, g.FP64, g.VARCHAR
 
 
 def clobbered_cells(t: pl.ColumnarTable):
@@ -29,7 +29,7 @@ def clobbered_cells(t: pl.ColumnarTable):
     (NULL-bearing INT64 / FP64 columns only; IMDB has none)."""
     out = set()
     for ci, c in enumerate(t.columns):
-        if c.type != I64:
+        if c.type not in (I64, F64):
             continue
         r = 0
         for p in c.pages:
@@ -42,6 +42,13 @@ def clobbered_cells(t: pl.ColumnarTable):
     return out
 
 
+def bitwise(rows):
+    """expected rows with every double replaced by ("f64", its bits), as rows_of() reports them"""
+    import struct
+
+    return [tuple(("f64", struct.unpack("<Q", struct.pack("<d", float(v)))[0]) if isinstance(v, float) else v for v in row) for row in rows]
+
+
 def rows_of(t: pl.ColumnarTable, expect=None):
     """decoded rows; with `expect`, the cells clobbered_cells() names take the expected value"""
     cols = []
@@ -50,7 +57,11 @@ def rows_of(t: pl.ColumnarTable, expect=None):
             cols.append(pg.unpack_varchar(c.pages, t.num_rows))
         else:
             v, m = pg.unpack_fixed(c.pages, t.num_rows, c.type)
-            cols.append([int(v[i]) if m[i] else None for i in range(t.num_rows)])
+            if c.type == F64:  # doubles compare by their bits (-0.0 is not 0.0 here)
+                b = np.asarray(v).view(np.uint64)
+                cols.append([("f64", int(b[i])) if m[i] else None for i in range(t.num_rows)])
+            else:
+                cols.append([int(v[i]) if m[i] else None for i in range(t.num_rows)])
     if expect is not None:
         for r, ci in clobbered_cells(t):
             cols[ci][r] = expect[r][ci]
@@ -82,19 +93,31 @@ def test_dialect_by_hand():
 @pytest.mark.parametrize("seed", range(12))
 def test_random_tables_roundtrip_and_filters(seed):
     rng = np.random.default_rng(seed)
-    types = [[I32, VC, I64], [VC, I32], [I32, I32, VC, VC], [I64]][seed % 4]
+    types = [[I32, VC, I64], [VC, I32], [I32, I32, VC, VC], [I64], [F64, I32], [VC, F64, F64]][seed % 6]
     n = int(rng.integers(1, 4000))
     rows = g.random_rows(rng, n, types, null_p=0.15, long_p=0.002 if seed % 3 == 0 else 0.0)
     if len(types) == 1:  # a one-column table cannot tell a NULL row from an empty line: keep both legal
         rows = [r for r in rows if r[0] is not None] or [(1,)]
     text = g.to_csv(rng, rows, final_newline=bool(seed & 1))
-    assert rows_of(_oracle.from_csv(text, types), rows) == rows
+    assert rows_of(_oracle.from_csv(text, types), bitwise(rows)) == bitwise(rows)
     for _ in range(4):
         prog = g.random_filter(rng, rows, types)
         want = [row for r, row in enumerate(rows) if g.eval_filter(prog, row, r)]
         got = _oracle.from_csv(text, types, prog)
         assert got.num_rows == len(want)
-        assert rows_of(got, want) == want
+        assert rows_of(got, bitwise(want)) == bitwise(want)
+
+
+def test_fp64_fields_by_hand():
+    """std::from_chars(double): the longest numeric prefix, no '+', inf / nan in any case, the nearest
+    double; an empty field is NULL"""
+    text = b'1.5\n-0\n"2.5e3"\n\n.5\n5.\n12abc\n1e\n0x10\ninf\n-Infinity\n9007199254740993\n4.9e-324\n1e-320\n1.5.2\n'
+    t = _oracle.from_csv(text + b"7\n", [F64])  # (a last row, so that the empty line before is a row of its own)
+    got = rows_of(t)
+    want = [1.5, -0.0, 2500.0, None, 0.5, 5.0, 12.0, 1.0, 0.0, float("inf"), float("-inf"), 9007199254740992.0, 5e-324, 1e-320, 1.5, 7.0]
+    assert got == bitwise([(w,) for w in want])
+    v, m = pg.unpack_fixed(_oracle.from_csv(b"nan\n-nan\nNaN(7)x\n", [F64]).columns[0].pages, 3, F64)
+    assert m.all() and np.isnan(v).all()
 
 
 def _page_shapes(col: pl.Column):
@@ -165,6 +188,12 @@ def test_every_closed_page_is_full(seed):
     (b"1,-\n", [I32, I32], "parse integer error"),
     (b"1,2147483648\n", [I32, I32], "parse integer error"),    # out of range for INT32
     (b"1,9223372036854775808\n", [I32, I64], "parse integer error"),
+    (b"1,x\n", [I32, F64], "parse float error"),
+    (b"1,+5\n", [I32, F64], "parse float error"),               # std::from_chars takes no '+'
+    (b"1, 5\n", [I32, F64], "parse float error"),               # ... and skips no white space
+    (b"1,.\n", [I32, F64], "parse float error"),
+    (b"1,1e999\n", [I32, F64], "parse float error"),            # result_out_of_range: overflow
+    (b"1,1e-999\n", [I32, F64], "parse float error"),           # ... and non-zero text that rounds to zero
 ])
 def test_errors_as_the_reference_raises_them(text, types, msg):
     with pytest.raises(RuntimeError) as e:
