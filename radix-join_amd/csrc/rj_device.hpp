@@ -84,8 +84,15 @@ constexpr int PT_ITEMS   = RJ_PT_ITEMS;           // tuples per thread per tile
 constexpr int PT_TILE    = PT_THREADS * PT_ITEMS; // 16384 tuples = 64 KiB of LDS staging; longer
                                                   // digit runs per tile = fewer partial HBM lines
 constexpr uint32_t PT_ALL_ITEMS = PT_ITEMS >= 32 ? 0xffffffffu : ((1u << (PT_ITEMS & 31)) - 1u);  // one bit per item
-constexpr int PT_MAXF    = 512;                   // max fan-out per pass (9 bits)
-constexpr int PT_MAXBITS = 9;
+// what the kernels can fan out per pass; -DRJ_PT_CAPBITS=10 builds the 1024-digit variant that
+// RJ_TUNE_P1_BITS=8 / 10 needs to cut 18 bits 8+10 / 10+8 (profiles/r03_r_bits_8_10_ab.log: no gain)
+#ifndef RJ_PT_CAPBITS
+#define RJ_PT_CAPBITS 9
+#endif
+constexpr int PT_CAPBITS = RJ_PT_CAPBITS;
+constexpr int PT_MAXF    = 1 << PT_CAPBITS;
+constexpr int PT_MAXBITS = 9;                     // what the bit plans use per pass (512 digits: runs of 32 tuples per tile)
+static_assert(PT_CAPBITS >= PT_MAXBITS && PT_CAPBITS <= 10, "fan-out capacity");
 constexpr int PT_FINEBITS = 15;                   // fine (two-digit) histogram: 2^15 bins = 128 KiB of LDS
 constexpr int LDS_BYTES  = 160 * 1024;            // per CU (and the most one workgroup may declare)
 static_assert(PT_THREADS >= PT_MAXF, "thread d scans digit d");

@@ -153,8 +153,8 @@ class Exec {
     // rj_shard_partition: decode + hash + one pass over the TOP log2(n_ranks) hash bits
     void run_shard(const Table* t, uint64_t key_col, uint64_t carry_col, uint32_t n_ranks,
                    rj_tuples* out, uint64_t* counts) {
-        if (n_ranks == 0 || (n_ranks & (n_ranks - 1)) || n_ranks > PT_MAXF)
-            throw_fmt(RJ_ERR_UNSUPPORTED, "n_ranks must be a power of two <= %d", PT_MAXF);
+        if (n_ranks == 0 || (n_ranks & (n_ranks - 1)) || n_ranks > (1u << PT_MAXBITS))
+            throw_fmt(RJ_ERR_UNSUPPORTED, "n_ranks must be a power of two <= %d", 1 << PT_MAXBITS);
         if (key_col >= t->cols.size() || carry_col >= t->cols.size())
             throw_fmt(RJ_ERR_ARG, "column out of range");
         DCol k = table_col(t, (int)key_col), c = table_col(t, (int)carry_col);
@@ -345,7 +345,7 @@ class Exec {
         // tuning knobs (experiments): RJ_TUNE_P1_BITS moves bits between pass 1 and pass 2
         if (passes == 2 && ctx->tune.p1_bits > 0) {
             uint32_t b1 = (uint32_t)ctx->tune.p1_bits;
-            if (b1 < bits && b1 <= PT_MAXBITS && bits - b1 <= PT_MAXBITS) {
+            if (b1 < bits && b1 <= PT_CAPBITS && bits - b1 <= PT_CAPBITS) {
                 pbits[0] = b1;
                 pbits[1] = bits - b1;
             }
