@@ -190,7 +190,10 @@ static_assert(JN_CAP * 4 * 4 + JN_CAP + 1024 <= 160 * 1024, "a four-array join t
 // overlap by themselves (pipelining them only spilled); tables of 3+ arrays run ONE 1024-thread
 // workgroup per CU, which would otherwise serialise load latency, build, probe and emit.
 constexpr int jn_ppw(int table_words) { return table_words >= 3 ? RJ_JN_PPW3 : RJ_JN_PPW; }
-constexpr uint32_t JN_HEAVY   = 32768;                 // probe tuples per task before splitting
+#ifndef RJ_JN_HEAVY
+#define RJ_JN_HEAVY 65536  // (16 K / 32 K / 64 K / 128 K at 1 B rows, Zipf 0.9: join 9.30 / 9.16 / 9.03 / 9.11 ms — profiles/r03_v_*)
+#endif
+constexpr uint32_t JN_HEAVY   = RJ_JN_HEAVY;           // probe tuples per task before splitting
 constexpr uint32_t JN_TARGET_BUILD = JN_RMAX * 3 / 4;  // mean build tuples per final partition
 
 enum StreamMode : int32_t {

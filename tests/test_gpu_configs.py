@@ -34,7 +34,7 @@ def test_config3_shape_zipf_probe_int64_payload(ctx):
     bk = rng.permutation(nb).astype(np.int32)
     ranks = zipf_ranks(rng, nb, npr)
     pk = ((ranks * 7919 + 13) % nb).astype(np.int32)  # bijection: hot keys not adjacent
-    assert np.bincount(pk.astype(np.int64), minlength=nb).max() > 40_000
+    assert np.bincount(pk.astype(np.int64), minlength=nb).max() > 70_000  # JN_HEAVY = 65536
     bt = pl.make_table([(pl.INT32, bk), (pl.INT64, rng.integers(-(2**62), 2**62, nb).astype(np.int64))])
     pt = pl.make_table([(pl.INT32, pk), (pl.INT64, rng.integers(-(2**62), 2**62, npr).astype(np.int64))])
     p = pl.Plan()
