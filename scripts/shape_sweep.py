@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""No-cliff check across join shapes the hot path specialises for: one JoinNode, N x N rows (unique
+build keys, every probe key hits once unless stated), inputs resident in HBM, result left in HBM.
+Prints G probe tuples/s and ms per join for each shape — key type, payload columns per side, NULLs,
+duplicates — so that a shape that falls off the fast paths (row-index carries + gather, 64-bit
+keys, three- and four-word tuples) shows next to the BASELINE shapes.
+    python scripts/shape_sweep.py [rows]        (default 100 M; on the GPU box)"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "radix-join_amd"))
+from pyrj import capi  # noqa: E402
+from pyrj import plan as pl  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
+I32, I64, F64 = pl.INT32, pl.INT64, pl.FP64
+NP = {I32: np.int32, I64: np.int64, F64: np.float64}
+rng = np.random.default_rng(1)
+
+
+def keycol(kt, base):
+    if kt == I32:
+        return base.astype(np.int32)
+    if kt == I64:
+        return base.astype(np.int64) * 4_000_000_007 - 12345
+    return base.astype(np.float64) * 0.5 - 1000.0
+
+
+def paycol(dt, n, null=0.0):
+    v = rng.integers(-(2**30), 2**30, n).astype(NP[dt])
+    return (dt, v, rng.random(n) >= null) if null else (dt, v)
+
+
+SHAPES = [
+    # name, key type, build payloads, probe payloads, build-key duplication, NULL fraction of the first build payload
+    ("k32 | 32 / 32   (config 2)", I32, [I32], [I32], 1, 0.0),
+    ("k32 | 64 / 64   (config 3)", I32, [I64], [I64], 1, 0.0),
+    ("k32 | 32 / 64", I32, [I32], [I64], 1, 0.0),
+    ("k64 | 32 / 32", I64, [I32], [I32], 1, 0.0),
+    ("k64 | 64 / 64", I64, [I64], [I64], 1, 0.0),
+    ("f64 | 32 / 32", F64, [I32], [I32], 1, 0.0),
+    ("k32 | 32+32 / 32   (wide, 2 words)", I32, [I32, I32], [I32], 1, 0.0),
+    ("k32 | 32+64 / 32   (wide, 3 words)", I32, [I32, I64], [I32], 1, 0.0),
+    ("k32 | 32 (10% NULL) / 32   (wide: value + validity)", I32, [I32], [I32], 1, 0.1),
+    ("k32 | 32+64+32 / 32   (row index + gather)", I32, [I32, I64, I32], [I32], 1, 0.0),
+    ("k32 | 32 / 32, every build key twice", I32, [I32], [I32], 2, 0.0),
+    ("k32 | - / -   (keys only)", I32, [], [], 1, 0.0),
+]
+
+
+def run(ctx, name, kt, bpay, ppay, dup, null):
+    nb = N
+    dom = nb // dup
+    bbase = rng.permutation(dom)
+    if dup > 1:
+        bbase = np.concatenate([bbase] * dup)
+    pbase = rng.integers(0, dom, N)
+    bcols = [(kt, keycol(kt, bbase))] + [paycol(dt, nb, null if i == 0 else 0.0) for i, dt in enumerate(bpay)]
+    pcols = [(kt, keycol(kt, pbase))] + [paycol(dt, N) for dt in ppay]
+    bt, pt = pl.make_table(bcols), pl.make_table(pcols)
+    p = pl.Plan()
+    b = p.new_scan_node(0, [(i, c[0]) for i, c in enumerate(bcols)])
+    s = p.new_scan_node(1, [(i, c[0]) for i, c in enumerate(pcols)])
+    both = [c[0] for c in bcols] + [c[0] for c in pcols]
+    out = [(i, t) for i, t in enumerate(both) if i != len(bcols)]  # the probe side's key column once is enough
+    p.root = p.new_join_node(True, b, s, 0, 0, out)
+    p.new_input(bt)
+    p.new_input(pt)
+    B, S = ctx.upload(bt), ctx.upload(pt)
+    del bt, pt, bcols, pcols
+    rows = None
+    for _ in range(2):
+        r = ctx.execute_resident(p, [B, S])
+        rows = r.num_rows
+        r.free()
+    t0 = time.perf_counter()
+    K = 5
+    for _ in range(K):
+        ctx.execute_resident(p, [B, S]).free()
+    ms = (time.perf_counter() - t0) / K * 1e3
+    B.release()
+    S.release()
+    assert rows == N * dup, (rows, N * dup)
+    print("%-58s %8.2f ms  %6.2f G probe tuples/s" % (name, ms, N / ms / 1e6), flush=True)
+
+
+def main():
+    ctx = capi.Context()
+    print(f"{N} x {N} rows, inputs resident, result left in HBM; 5 timed joins after 2 warm-ups")
+    for sh in SHAPES:
+        run(ctx, *sh)
+    capi.destroy_context(ctx)
+
+
+if __name__ == "__main__":
+    main()
