@@ -4,7 +4,9 @@ build keys, every probe key hits once unless stated), inputs resident in HBM, re
 Prints G probe tuples/s and ms per join for each shape — key type, payload columns per side, NULLs,
 duplicates — so that a shape that falls off the fast paths (row-index carries + gather, 64-bit
 keys, three- and four-word tuples) shows next to the BASELINE shapes.
-    python scripts/shape_sweep.py [rows]        (default 100 M; on the GPU box)"""
+    python scripts/shape_sweep.py [rows]        (default 100 M; on the GPU box)
+RJ_SWEEP_PROFILE=1 adds the per-kernel milliseconds of one join per shape (timed runs then carry the
+profiler's events)."""
 import os
 import sys
 import time
@@ -18,6 +20,7 @@ from pyrj import plan as pl  # noqa: E402
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
 I32, I64, F64 = pl.INT32, pl.INT64, pl.FP64
 NP = {I32: np.int32, I64: np.int64, F64: np.float64}
+PROFILE = os.environ.get("RJ_SWEEP_PROFILE") == "1"
 rng = np.random.default_rng(1)
 
 
@@ -81,14 +84,18 @@ def run(ctx, name, kt, bpay, ppay, dup, null):
     for _ in range(K):
         ctx.execute_resident(p, [B, S]).free()
     ms = (time.perf_counter() - t0) / K * 1e3
-    B.release()
-    S.release()
     assert rows == N * dup, (rows, N * dup)
     print("%-58s %8.2f ms  %6.2f G probe tuples/s" % (name, ms, N / ms / 1e6), flush=True)
+    if PROFILE:  # per-kernel ms of one more join (the library brackets every launch)
+        ctx.profile_reset()
+        ctx.execute_resident(p, [B, S]).free()
+        print("      " + "  ".join("%s=%.2f" % (k["name"], k["total_ms"]) for k in ctx.profile() if k["total_ms"] >= 0.02), flush=True)
+    B.release()
+    S.release()
 
 
 def main():
-    ctx = capi.Context()
+    ctx = capi.Context(profile=PROFILE)
     print(f"{N} x {N} rows, inputs resident, result left in HBM; 5 timed joins after 2 warm-ups")
     for sh in SHAPES:
         run(ctx, *sh)
