@@ -244,7 +244,7 @@ struct SplitParams {
         int32_t  word;           // first word of the column inside the record
         int32_t  width;          // 4 or 8
         int32_t  valid_bit;
-        int32_t  pad;
+        int32_t  paged;          // 1: `out` is a run of Page images (values at their slot), 0: a dense array
     } col[3];
 };
 

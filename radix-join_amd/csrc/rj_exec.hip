@@ -629,6 +629,7 @@ class Exec {
             BufP             vword;  // the packed validity word per row of the child
             struct WideOut {
                 BufP values, valid;
+                int  mode = ST_NONE;  // dense values, or — root columns without NULLs — Page images straight away
             };
             std::map<int, WideOut> wide_out;  // per carried column: what k_split_records produced
         };
@@ -1019,13 +1020,18 @@ class Exec {
             for (size_t i = 0; i < s->wide_cols.size(); ++i) {
                 const DCol&   col = s->rel->cols[s->wide_cols[i]];
                 Side::WideOut wo;
-                wo.values = ctx->buf(std::max<uint64_t>(nrows, 1) * col.width);
+                // a root column without NULLs goes into its Page images here (the header words are
+                // filled in below), anything else into a dense array
+                const bool to_pages = is_root && !col.valid && col.type != RJ_VARCHAR;  // (a VARCHAR column travels as row ids)
+                wo.mode = to_pages ? (col.width == 4 ? ST_PAGED32 : ST_PAGED64) : (col.width == 4 ? ST_DENSE32 : ST_DENSE64);
+                wo.values = ctx->buf(stream_bytes(wo.mode, std::max<uint64_t>(nrows, 1)));
                 if (col.valid) wo.valid = ctx->buf(std::max<uint64_t>(nrows, 1));
                 sp.col[i].out = wo.values->as<uint8_t>();
                 sp.col[i].valid = wo.valid ? wo.valid->as<uint8_t>() : nullptr;
                 sp.col[i].word = word;
                 sp.col[i].width = col.width;
                 sp.col[i].valid_bit = (int32_t)i;
+                sp.col[i].paged = to_pages ? 1 : 0;
                 word += col.width / 4;
                 s->wide_out[s->wide_cols[i]] = wo;
             }
@@ -1061,7 +1067,7 @@ class Exec {
                 const Side::WideOut& wo = s.wide_out.at(c);
                 buf = wo.values;
                 valid = wo.valid;
-                buf_mode = src.width == 4 ? ST_DENSE32 : ST_DENSE64;
+                buf_mode = wo.mode;
             } else {
                 // generic path: gather the child column through the row-index stream
                 const uint32_t* idx = s.stream->as<uint32_t>();

@@ -2358,7 +2358,10 @@ __global__ __launch_bounds__(256) void k_split_records(SplitParams sp, uint64_t 
     for (int c = 0; c < 3; ++c) {
         if (c >= sp.n_cols) break;
         const uint32_t lo = r[sp.col[c].word];
-        if (sp.col[c].width == 8)
+        if (sp.col[c].paged)
+            stream_store(OutStream{sp.col[c].out, sp.col[c].width == 8 ? ST_PAGED64 : ST_PAGED32, 0}, i, lo,
+                         sp.col[c].width == 8 ? r[sp.col[c].word + 1] : 0u);
+        else if (sp.col[c].width == 8)
             reinterpret_cast<uint64_t*>(sp.col[c].out)[i] = (uint64_t)lo | ((uint64_t)r[sp.col[c].word + 1] << 32);
         else
             reinterpret_cast<uint32_t*>(sp.col[c].out)[i] = lo;

@@ -348,7 +348,7 @@ class Context:
             return
         self.group = None
         cfg = rj_config()
-        cfg.device, cfg.profile, cfg.stream, cfg.radix_bits = device, 1 if profile else 0, stream, radix_bits
+        cfg.device, cfg.profile, cfg.stream, cfg.radix_bits = device, int(profile), stream, radix_bits  # 1: the hot kernels, 2: every launch
         if devices is not None:
             self._devs = (C.c_int32 * len(devices))(*devices)
             cfg.n_devices, cfg.devices = len(devices), self._devs

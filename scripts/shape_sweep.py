@@ -89,16 +89,18 @@ def run(ctx, name, kt, bpay, ppay, dup, null):
     if PROFILE:  # per-kernel ms of one more join (the library brackets every launch)
         ctx.profile_reset()
         ctx.execute_resident(p, [B, S]).free()
-        print("      " + "  ".join("%s=%.2f" % (k["name"], k["total_ms"]) for k in ctx.profile() if k["total_ms"] >= 0.02), flush=True)
+        print("      " + "  ".join("%s=%.2f" % (k["name"], k["total_ms"]) for k in ctx.profile() if k["total_ms"] >= 0.005), flush=True)
     B.release()
     S.release()
 
 
 def main():
-    ctx = capi.Context(profile=PROFILE)
+    ctx = capi.Context(profile=2 if PROFILE else False)  # 2: every kernel, not only the hot five
     print(f"{N} x {N} rows, inputs resident, result left in HBM; 5 timed joins after 2 warm-ups")
-    for sh in SHAPES:
-        run(ctx, *sh)
+    only = os.environ.get("RJ_SWEEP_ONLY")  # e.g. "0,6": shapes by index
+    for i, sh in enumerate(SHAPES):
+        if only is None or str(i) in only.split(","):
+            run(ctx, *sh)
     capi.destroy_context(ctx)
 
 
