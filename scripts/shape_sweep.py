@@ -51,6 +51,7 @@ SHAPES = [
     ("k32 | 32+64+32 / 32   (row index + gather)", I32, [I32, I64, I32], [I32], 1, 0.0),
     ("k32 | 32 / 32, every build key twice", I32, [I32], [I32], 2, 0.0),
     ("k32 | - / -   (keys only)", I32, [], [], 1, 0.0),
+    ("k32 | 64 / 32   (the tuple layouts of the 2-word wide shape, one column)", I32, [I64], [I32], 1, 0.0),
 ]
 
 
