@@ -95,6 +95,51 @@ def run(ctx, name, kt, bpay, ppay, dup, null):
     S.release()
 
 
+def run_tree(ctx, name, n, wide):
+    """(A join B) join C, n rows each: B.k -> A.k (every B row finds its A row), then the result's
+    B.fk -> C.k.  `wide`: the first join hands two payload columns per side to the second."""
+    a_k = rng.permutation(n).astype(np.int32)
+    c_k = rng.permutation(n).astype(np.int32)
+    acols = [(I32, a_k), paycol(I32, n)] + ([paycol(I64, n)] if wide else [])
+    bcols = [(I32, rng.integers(0, n, n).astype(np.int32)), (I32, rng.integers(0, n, n).astype(np.int32)), paycol(I32, n)]
+    ccols = [(I32, c_k), paycol(I64, n)]
+    ta, tb, tc = pl.make_table(acols), pl.make_table(bcols), pl.make_table(ccols)
+    p = pl.Plan()
+    sa = p.new_scan_node(0, [(i, c[0]) for i, c in enumerate(acols)])
+    sb = p.new_scan_node(1, [(i, c[0]) for i, c in enumerate(bcols)])
+    na = len(acols)
+    # out of the first join: A's payloads, B.fk, B.y
+    out1 = [(i, acols[i][0]) for i in range(1, na)] + [(na + 1, I32), (na + 2, I32)]
+    j1 = p.new_join_node(True, sa, sb, 0, 0, out1)
+    sc = p.new_scan_node(2, [(0, I32), (1, I64)])
+    n1 = len(out1)
+    fk_at = n1 - 2
+    out2 = [(i, out1[i][1]) for i in range(n1)] + [(n1 + 1, I64)]
+    p.root = p.new_join_node(False, j1, sc, fk_at, 0, out2)  # probe = the intermediate, build = C
+    for t in (ta, tb, tc):
+        p.new_input(t)
+    T = [ctx.upload(t) for t in (ta, tb, tc)]
+    del ta, tb, tc
+    rows = None
+    for _ in range(2):
+        r = ctx.execute_resident(p, T)
+        rows = r.num_rows
+        r.free()
+    t0 = time.perf_counter()
+    K = 5
+    for _ in range(K):
+        ctx.execute_resident(p, T).free()
+    ms = (time.perf_counter() - t0) / K * 1e3
+    assert rows == n, (rows, n)
+    print("%-58s %8.2f ms  %6.2f G rows/s through two joins" % (name, ms, n / ms / 1e6), flush=True)
+    if PROFILE:
+        ctx.profile_reset()
+        ctx.execute_resident(p, T).free()
+        print("      " + "  ".join("%s=%.2f" % (k["name"], k["total_ms"]) for k in ctx.profile() if k["total_ms"] >= 0.005), flush=True)
+    for t in T:
+        t.release()
+
+
 def main():
     ctx = capi.Context(profile=2 if PROFILE else False)  # 2: every kernel, not only the hot five
     print(f"{N} x {N} rows, inputs resident, result left in HBM; 5 timed joins after 2 warm-ups")
@@ -102,6 +147,9 @@ def main():
     for i, sh in enumerate(SHAPES):
         if only is None or str(i) in only.split(","):
             run(ctx, *sh)
+    if only is None or "tree" in only.split(","):
+        run_tree(ctx, "(A x B) x C, one payload column per table", N // 2, False)
+        run_tree(ctx, "(A x B) x C, A carries INT32 + INT64 (wide)", N // 2, True)
     capi.destroy_context(ctx)
 
 
