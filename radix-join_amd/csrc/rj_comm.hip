@@ -410,14 +410,23 @@ void Comm::allgather_u64(const std::vector<std::vector<uint64_t>>& vals, size_t 
         memcpy(hin + (size_t)l * k, vals[l].data(), k * 8);
         RJ_HIP(hipMemcpyAsync(cnt_dev_[l], hin + (size_t)l * k, k * 8, hipMemcpyHostToDevice, xfer_[l]));
     }
-    bounded("count all-gather (ncclAllGather)", [&] {
-        if (nl > 1) RJ_NCCL(R.GroupStart());
-        for (int l = 0; l < nl; ++l) {
-            RJ_HIP(hipSetDevice(lanes_[l]->device));
-            uint64_t* base = static_cast<uint64_t*>(cnt_dev_[l]);
-            RJ_NCCL(R.AllGather(base, base + k, k, ncclUint64, static_cast<ncclComm_t>(nccl_[l]), xfer_[l]));
+    struct Op {  // (by value into the helper thread, as in all_to_all)
+        int         dev;
+        uint64_t*   base;
+        ncclComm_t  comm;
+        hipStream_t stream;
+    };
+    auto ops = std::make_shared<std::vector<Op>>();
+    for (int l = 0; l < nl; ++l)
+        ops->push_back(Op{lanes_[l]->device, static_cast<uint64_t*>(cnt_dev_[l]), static_cast<ncclComm_t>(nccl_[l]), xfer_[l]});
+    Rccl* const rp = &R;
+    bounded("count all-gather (ncclAllGather)", [ops, rp, k] {
+        if (ops->size() > 1) RJ_NCCL(rp->GroupStart());
+        for (const Op& op : *ops) {
+            RJ_HIP(hipSetDevice(op.dev));
+            RJ_NCCL(rp->AllGather(op.base, op.base + k, k, ncclUint64, op.comm, op.stream));
         }
-        if (nl > 1) RJ_NCCL(R.GroupEnd());
+        if (ops->size() > 1) RJ_NCCL(rp->GroupEnd());
     });
     RJ_HIP(hipSetDevice(lanes_[0]->device));
     RJ_HIP(hipMemcpyAsync(cnt_host_, static_cast<uint64_t*>(cnt_dev_[0]) + k, (size_t)world_ * k * 8,
@@ -482,22 +491,42 @@ void Comm::all_to_all(const std::vector<std::vector<XferSpec>>& specs, const std
         // slices travel in pieces of at most 1 GiB (both ends cut the same total the same
         // way): multi-GiB point-to-point operations are outside what RCCL is exercised with
         constexpr uint64_t PIECE = 1ull << 30;
-        bounded(name, [&] {
-            RJ_NCCL(R.GroupStart());
-            for (int l = 0; l < nl; ++l) {
-                RJ_HIP(hipSetDevice(lanes_[l]->device));
-                ncclComm_t c = static_cast<ncclComm_t>(nccl_[l]);
-                for (const XferSpec& X : specs[l])
-                    for (int p = 0; p < world_; ++p) {
-                        for (uint64_t o = 0; o < X.send_cnt[p]; o += PIECE)
-                            RJ_NCCL(R.Send(X.send + X.send_off[p] + o, std::min(PIECE, X.send_cnt[p] - o), ncclUint8, p, c,
-                                           xfer_[l]));
-                        for (uint64_t o = 0; o < X.recv_cnt[p]; o += PIECE)
-                            RJ_NCCL(R.Recv(X.recv + X.recv_off[p] + o, std::min(PIECE, X.recv_cnt[p] - o), ncclUint8, p, c,
-                                           xfer_[l]));
-                    }
+        // The helper thread gets the operations BY VALUE: should the wait below expire and the helper
+        // have to be given up inside RCCL, it must not wake up later to references into this frame.
+        struct Op {
+            int         dev;
+            ncclComm_t  comm;
+            hipStream_t stream;
+            uint8_t*    ptr;
+            uint64_t    bytes;
+            int         peer;
+            bool        send;
+        };
+        auto ops = std::make_shared<std::vector<Op>>();
+        for (int l = 0; l < nl; ++l) {
+            ncclComm_t c = static_cast<ncclComm_t>(nccl_[l]);
+            for (const XferSpec& X : specs[l])
+                for (int p = 0; p < world_; ++p) {
+                    for (uint64_t o = 0; o < X.send_cnt[p]; o += PIECE)
+                        ops->push_back(Op{lanes_[l]->device, c, xfer_[l], const_cast<uint8_t*>(X.send) + X.send_off[p] + o,
+                                          std::min(PIECE, X.send_cnt[p] - o), p, true});
+                    for (uint64_t o = 0; o < X.recv_cnt[p]; o += PIECE)
+                        ops->push_back(Op{lanes_[l]->device, c, xfer_[l], X.recv + X.recv_off[p] + o,
+                                          std::min(PIECE, X.recv_cnt[p] - o), p, false});
+                }
+        }
+        Rccl* const rp = &R;  // (process lifetime)
+        bounded(name, [ops, rp] {
+            RJ_NCCL(rp->GroupStart());
+            int dev = -1;
+            for (const Op& op : *ops) {
+                if (op.dev != dev) RJ_HIP(hipSetDevice(dev = op.dev));
+                if (op.send)
+                    RJ_NCCL(rp->Send(op.ptr, op.bytes, ncclUint8, op.peer, op.comm, op.stream));
+                else
+                    RJ_NCCL(rp->Recv(op.ptr, op.bytes, ncclUint8, op.peer, op.comm, op.stream));
             }
-            RJ_NCCL(R.GroupEnd());
+            RJ_NCCL(rp->GroupEnd());
         });
         for (int l = 0; l < nl; ++l) {
             RJ_HIP(hipSetDevice(lanes_[l]->device));

@@ -903,20 +903,23 @@ Table* table_from_csv(Context* ctx, const char* text, uint64_t n_bytes, uint64_t
     {
         constexpr size_t CH = (size_t)32 << 20;
         uint8_t*         stage = static_cast<uint8_t*>(ctx->staging(2 * CH));
-        hipEvent_t       ev[2];
-        RJ_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
-        RJ_HIP(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+        struct Ev {  // (destroyed on every way out)
+            hipEvent_t e = nullptr;
+            ~Ev() {
+                if (e) (void)hipEventDestroy(e);
+            }
+        } ev[2];
+        RJ_HIP(hipEventCreateWithFlags(&ev[0].e, hipEventDisableTiming));
+        RJ_HIP(hipEventCreateWithFlags(&ev[1].e, hipEventDisableTiming));
         size_t k = 0;
         for (size_t o = 0; o < n_bytes; o += CH, ++k) {
             const size_t m = std::min(CH, (size_t)n_bytes - o);
-            if (k >= 2) (void)hipEventSynchronize(ev[k & 1]);
+            if (k >= 2) (void)hipEventSynchronize(ev[k & 1].e);
             memcpy(stage + (k & 1) * CH, text + o, m);
             RJ_HIP(hipMemcpyAsync(dtext->as<uint8_t>() + o, stage + (k & 1) * CH, m, hipMemcpyHostToDevice, ctx->stream));
-            RJ_HIP(hipEventRecord(ev[k & 1], ctx->stream));
+            RJ_HIP(hipEventRecord(ev[k & 1].e, ctx->stream));
         }
         ctx->sync();
-        (void)hipEventDestroy(ev[0]);
-        (void)hipEventDestroy(ev[1]);
         if (add_nl) RJ_HIP(hipMemsetAsync(dtext->as<uint8_t>() + n_bytes, '\n', 1, ctx->stream));
     }
     const uint8_t* t = dtext->as<uint8_t>();
