@@ -632,7 +632,23 @@ class Exec {
                 int  mode = ST_NONE;  // dense values, or — root columns without NULLs — Page images straight away
             };
             std::map<int, WideOut> wide_out;  // per carried column: what k_split_records produced
+            // A sharded join's ranks must cut their tuples alike, and whether a column needs a validity
+            // word depends on the DATA of a shard: columns that hold NULLs on ANY rank are nullable on
+            // every rank (bit c = column c; columns from 64 up count as nullable when `shared` is set)
+            uint64_t null_mask = 0;
+            bool     shared = false;
+            bool     nullable(int c) const {
+                if (rel->cols[c].valid != nullptr) return true;
+                return shared && (c >= 64 || ((null_mask >> c) & 1u));
+            }
         };
+        // which of a relation's (first 64) columns hold NULLs here
+        static uint64_t null_columns(const Rel& r) {
+            uint64_t m = 0;
+            for (size_t c = 0; c < r.cols.size() && c < 64; ++c)
+                if (r.cols[c].valid != nullptr) m |= 1ull << c;
+            return m;
+        }
 
         static uint64_t pages_for(uint64_t rows, int width) {
             uint64_t rf = width == 4 ? ROWS32 : ROWS64;
@@ -685,7 +701,9 @@ class Exec {
             Side&    ps() { return build_left ? rs : ls; }
         };
 
-        void join_prepare(Rel& left, Rel& right, const JoinSpec& js, bool is_root, JoinState& st) {
+        // shared_nulls (sharded joins): {left, right} null_columns() OR-ed over all ranks
+        void join_prepare(Rel& left, Rel& right, const JoinSpec& js, bool is_root, JoinState& st,
+                          const uint64_t* shared_nulls = nullptr) {
             const size_t lw = left.cols.size(), rw = right.cols.size();
             st.lw = lw;
             st.rw = rw;
@@ -705,6 +723,11 @@ class Exec {
             ls.key_col = js.left_attr;
             rs.rel = &right;
             rs.key_col = js.right_attr;
+            if (shared_nulls) {
+                ls.shared = rs.shared = true;
+                ls.null_mask = shared_nulls[0];
+                rs.null_mask = shared_nulls[1];
+            }
             const DCol& bk = st.bs().rel->cols[st.bs().key_col];
             const DCol& pk = st.ps().rel->cols[st.ps().key_col];
             // KeyType = build side's key type (:271-273)
@@ -733,7 +756,7 @@ class Exec {
                 } else if (s->need.empty()) {
                     s->carry_mode = CARRY_NONE;
                     s->CW = 0;
-                } else if (s->need.size() == 1 && s->rel->cols[*s->need.begin()].valid == nullptr) {
+                } else if (s->need.size() == 1 && !s->nullable(*s->need.begin())) {
                     s->carry_mode = CARRY_COLUMN;
                     s->carry_col = *s->need.begin();
                     s->CW = s->rel->cols[s->carry_col].width / 4;
@@ -760,7 +783,7 @@ class Exec {
                 if (col.width != 4 && col.width != 8) return false;
                 words += col.width / 4;
                 n64 += col.width == 8;
-                any_null = any_null || col.valid != nullptr;
+                any_null = any_null || s.nullable(c);
             }
             if (any_null) ++words;
             if (words < 2 || words > MAX_WORDS - KW || n64 > 1 || (n64 == 1 && words != 3)) return false;
@@ -1022,10 +1045,11 @@ class Exec {
                 Side::WideOut wo;
                 // a root column without NULLs goes into its Page images here (the header words are
                 // filled in below), anything else into a dense array
-                const bool to_pages = is_root && !col.valid && col.type != RJ_VARCHAR;  // (a VARCHAR column travels as row ids)
+                const bool nullable = s->nullable(s->wide_cols[i]);  // (here, or on another rank of a sharded join)
+                const bool to_pages = is_root && !nullable && col.type != RJ_VARCHAR;  // (a VARCHAR column travels as row ids)
                 wo.mode = to_pages ? (col.width == 4 ? ST_PAGED32 : ST_PAGED64) : (col.width == 4 ? ST_DENSE32 : ST_DENSE64);
                 wo.values = ctx->buf(stream_bytes(wo.mode, std::max<uint64_t>(nrows, 1)));
-                if (col.valid) wo.valid = ctx->buf(std::max<uint64_t>(nrows, 1));
+                if (nullable) wo.valid = ctx->buf(std::max<uint64_t>(nrows, 1));
                 sp.col[i].out = wo.values->as<uint8_t>();
                 sp.col[i].valid = wo.valid ? wo.valid->as<uint8_t>() : nullptr;
                 sp.col[i].word = word;
@@ -1480,12 +1504,21 @@ class ShardedExec {
         // ---- what every rank decides locally, then agrees on globally
         std::vector<LocalErr>              lerr((size_t)nl_);
         std::vector<std::vector<uint64_t>> mine((size_t)nl_), all;
+        // which columns hold NULLs on ANY rank: the carry layout (a validity word or not, one column
+        // as it is or value + validity) follows the data, and every rank must pick the same one
+        uint64_t shared_nulls[2] = {0, 0};
+        for (int l = 0; l < nl_; ++l) mine[l] = {Exec::null_columns(left[l]), Exec::null_columns(right[l])};
+        gather(mine, 2, all);
+        for (int r = 0; r < world_; ++r) {
+            shared_nulls[0] |= all[r][0];
+            shared_nulls[1] |= all[r][1];
+        }
         for (int l = 0; l < nl_; ++l) {
             bool ok = true;
             guarded(lerr[l], [&] {
                 use(l);
                 inject_failure(1, l);
-                ex_[l]->join_prepare(left[l], right[l], js, root_res != nullptr, st[l]);
+                ex_[l]->join_prepare(left[l], right[l], js, root_res != nullptr, st[l], shared_nulls);
                 for (Exec::Side* s : {&st[l].ls, &st[l].rs}) {
                     if (s->carry_mode == CARRY_ROWIDX) ok = false;  // a row index means nothing on another rank
                     if (s->carry_mode == CARRY_COLUMN && s->rel->cols[s->carry_col].kind == COL_IOTA) ok = false;

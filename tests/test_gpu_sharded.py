@@ -239,6 +239,33 @@ def test_wide_carries_shard(n_ranks):
     check_against_oracle(p, n_ranks)
 
 
+@pytest.mark.parametrize("n_ranks", [2, 4])
+def test_nulls_on_one_rank_only(n_ranks):
+    """Whether a payload column needs a validity word depends on the data of a shard: here the build
+    side's only payload column holds NULLs in the FIRST rank's rows alone (elsewhere it could travel
+    as it is, CARRY_COLUMN), and one of the probe side's two columns in the LAST rank's rows alone
+    (elsewhere two words instead of three).  The ranks agree on the union before they cut their
+    tuples (Side::null_mask), or the exchanged arrays would not even have the same width."""
+    rng = np.random.default_rng(90 + n_ranks)
+    nb, npr = 400_000, 900_000
+    bvalid = np.ones(nb, dtype=bool)
+    bvalid[: nb // (2 * n_ranks)] = rng.random(nb // (2 * n_ranks)) > 0.5
+    pvalid = np.ones(npr, dtype=bool)
+    pvalid[-(npr // (2 * n_ranks)):] = rng.random(npr // (2 * n_ranks)) > 0.4
+    bt = pl.make_table([(pl.INT32, rng.integers(0, 300_000, nb).astype(np.int32)),
+                        (pl.INT64, rng.integers(-(2**62), 2**62, nb).astype(np.int64), bvalid)])
+    pt = pl.make_table([(pl.INT32, rng.integers(0, 320_000, npr).astype(np.int32)),
+                        (pl.INT32, rng.integers(-(2**31), 2**31 - 1, npr).astype(np.int32), pvalid),
+                        (pl.INT32, np.arange(npr, dtype=np.int32))])
+    p = join_plan(bt, pt, [pl.INT32, pl.INT64], [pl.INT32, pl.INT32, pl.INT32],
+                  [(1, pl.INT64), (0, pl.INT32), (3, pl.INT32), (4, pl.INT32)])
+    assert capi.plan_shardable(p)[0]
+    check_against_oracle(p, n_ranks)
+    # ... and a single nullable INT32 column on the probe side (one word here, value + validity there)
+    p2 = join_plan(bt, pt, [pl.INT32, pl.INT64], [pl.INT32, pl.INT32, pl.INT32], [(0, pl.INT32), (3, pl.INT32)])
+    check_against_oracle(p2, n_ranks)
+
+
 def test_rccl_transport_at_world_size_one():
     """The RCCL code path (communicator from an rj_comm_id, count all-gather, grouped
     ncclSend/ncclRecv to self) on the one GPU this box has.  In a process of its own
