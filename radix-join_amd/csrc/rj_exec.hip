@@ -1314,15 +1314,20 @@ class Exec {
 
 
 // ================================================================ sharded executor
-// One JoinNode across the ranks of a job (SURVEY.md §8e): every rank
-//   stage A   forms (hashed key, carry) tuples of its shard of both children and partitions
-//             them by OWNER rank = top log2(world) hash bits (one radix pass, fan-out = world);
-//   exchange  ONE variable-size all-to-all per relation (rj_comm: peer copies or RCCL), on its
-//             own stream — the probe side's exchange runs behind the build side's radix passes;
-//   stage B   runs the remaining radix passes + build/probe on what arrived, exactly the
-//             single-device join on prehashed tuples whose top bits are constant.
-// Results stay on the owning rank (no reduction).  One host thread drives all local ranks
-// phase by phase; everything between the count read-backs is asynchronous.
+// One JoinNode across the ranks of a job (SURVEY.md §8e, DESIGN.md §6): every rank
+//   stage A   forms (hashed key, carry) tuples of its shard of both children and partitions them
+//             by (OWNER rank = top log2(world) hash bits, first local digit = low bits) in ONE radix
+//             pass (fan-out = world x 2^s <= 512; RJ_TUNE_FOLD_OWNER=0: by owner only);
+//   exchange  ONE variable-size all-to-all per relation (rj_comm: peer copies or RCCL), on its own
+//             stream — the build side's exchange overlaps the probe side's stage A, the probe side's
+//             the build side's stage B; its layout is host arithmetic over the all-gathered counts
+//             (rj_xplan.cpp);
+//   stage B   runs the remaining radix passes + build/probe on what arrived (the runs of a digit as
+//             input segments of its first pass), i.e. the single-device join on an N-th of the data.
+// Results stay on the owning rank (no reduction).  One host thread drives all local ranks phase by
+// phase; everything between the count read-backs is asynchronous.  What a rank decides from its own
+// DATA and that shapes what is exchanged (which columns need a validity word) is agreed on first;
+// local failures travel as status words with the counts, and every wait on a peer is bounded.
 class ShardedExec {
    public:
     ShardedExec(Context* group, const rj_plan* plan, Table* const* tables, uint64_t n_inputs, int flags)
@@ -1362,6 +1367,8 @@ class ShardedExec {
             } else {
                 (void)node(plan_->root, &rp, 0);
             }
+            for (const LocalErr& e : pending_)  // (cannot happen: a join above the scan has thrown it)
+                if (e.code) throw rj::Error(e.code, e.msg);
             sync_all();
         } catch (...) {
             // kernels and copies still queued may reference buffers about to be released
@@ -1416,11 +1423,17 @@ class ShardedExec {
         if (depth > 4096) throw_fmt(RJ_ERR_ARG, "plan too deep (cycle?)");
         const rj_node& n = plan_->nodes[idx];
         if (n.kind == RJ_NODE_SCAN) {
+            // a scan that fails on one rank (its shard's pages are malformed: "row_idx") must not
+            // leave the other ranks waiting in the next join's collectives: the error is kept and
+            // travels as that join's first status word
             std::vector<Rel> r((size_t)nl_);
-            for (int l = 0; l < nl_; ++l) {
-                use(l);
-                r[l] = ex_[l]->scan(n);
-            }
+            if (pending_.empty()) pending_.resize((size_t)nl_);
+            for (int l = 0; l < nl_; ++l)
+                guarded(pending_[l], [&] {
+                    use(l);
+                    inject_failure(5, l);
+                    r[l] = ex_[l]->scan(n);
+                });
             return r;
         }
         if (n.kind != RJ_NODE_JOIN) throw_fmt(RJ_ERR_ARG, "bad node kind");
@@ -1452,6 +1465,7 @@ class ShardedExec {
         int         code = 0;
         std::string msg;
     };
+    std::vector<LocalErr> pending_;  // per local rank: a scan's failure, waiting for the next join's status word
     template <class F>
     static void guarded(LocalErr& e, F&& f) {
         if (e.code) return;  // this rank failed earlier: it only keeps the collectives company
@@ -1503,6 +1517,7 @@ class ShardedExec {
         };
         // ---- what every rank decides locally, then agrees on globally
         std::vector<LocalErr>              lerr((size_t)nl_);
+        if (!pending_.empty()) lerr = pending_;  // (a scan below this join failed on a local rank)
         std::vector<std::vector<uint64_t>> mine((size_t)nl_), all;
         // which columns hold NULLs on ANY rank: the carry layout (a validity word or not, one column
         // as it is or value + validity) follows the data, and every rank must pick the same one
