@@ -1367,7 +1367,7 @@ class ShardedExec {
             } else {
                 (void)node(plan_->root, &rp, 0);
             }
-            for (const LocalErr& e : pending_)  // (cannot happen: a join above the scan has thrown it)
+            for (const LocalErr& e : pending_)  // (a failure of the last join's local part)
                 if (e.code) throw rj::Error(e.code, e.msg);
             sync_all();
         } catch (...) {
@@ -1766,19 +1766,27 @@ class ShardedExec {
             shape.prior_bits = {sbits};
             return E.partition(nullptr, &X.ws, KW, CW, Lbits - sbits, sbits, false, nullptr, nullptr, &shape);
         };
+        // (what fails on ONE rank from here on — an allocation, a result beyond 2^32 rows — is kept and
+        // reported with the next join's first status word, or at the end of the plan: the peers are
+        // not in a collective with this rank any more, but would be in the next join)
+        if (pending_.empty()) pending_.resize((size_t)nl_);
         for (int side = 0; side < 2; ++side)
             for (int l = 0; l < nl_; ++l) {
                 SideX& X = side == 0 ? bx[l] : px[l];
                 if (comm_) comm_->wait_event(l, X.done.e, side == 0 ? "the exchange of the build side" : "the exchange of the probe side");
-                use(l);
-                RJ_HIP(hipStreamWaitEvent(g_->lane(l)->stream, X.done.e, 0));
-                X.P = stage_b(l, X, side == 0 ? st[l].bs().CW : st[l].ps().CW);
+                guarded(pending_[l], [&] {
+                    use(l);
+                    RJ_HIP(hipStreamWaitEvent(g_->lane(l)->stream, X.done.e, 0));
+                    X.P = stage_b(l, X, side == 0 ? st[l].bs().CW : st[l].ps().CW);
+                });
             }
-        for (int l = 0; l < nl_; ++l) {
-            use(l);
-            st[l].cap_hint = std::max(bx[l].ws.n, px[l].ws.n);
-            out[l] = ex_[l]->join_finish(st[l], js, &bx[l].P, &px[l].P, Lbits, root_res ? (*root_res)[l] : nullptr);
-        }
+        for (int l = 0; l < nl_; ++l)
+            guarded(pending_[l], [&] {
+                use(l);
+                inject_failure(6, l);
+                st[l].cap_hint = std::max(bx[l].ws.n, px[l].ws.n);
+                out[l] = ex_[l]->join_finish(st[l], js, &bx[l].P, &px[l].P, Lbits, root_res ? (*root_res)[l] : nullptr);
+            });
         lap("stage B (passes + join)");
         // stage A's arrays were read by the exchange streams (and by peers): they may go back
         // to the block caches only now that every rank's outgoing copies have left

@@ -198,7 +198,7 @@ struct Tuning {
     int bringup_timeout_ms = 0;        // RJ_BRINGUP_TIMEOUT_MS: its own bound for the bring-up (0: the same) — in a
                                        // cold process RCCL takes seconds to load, a running exchange milliseconds
     // RJ_DEBUG_SHARD_FAIL (tests): global rank RJ_DEBUG_SHARD_FAIL_RANK fails locally at this point of a
-    // sharded join — 1: while preparing, 2: in stage A, 3: allocating its receive buffers, 5: in a scan below it; 4: it does not
+    // sharded join — 1: while preparing, 2: in stage A, 3: allocating its receive buffers, 5: in a scan below it, 6: building / probing what arrived; 4: it does not
     // fail but stalls (its probe-side slices are not ready for 7 s: the exchange's bounded wait expires)
     int debug_shard_fail = 0, debug_shard_fail_rank = 0;
     void from_env();

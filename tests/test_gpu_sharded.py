@@ -294,10 +294,11 @@ def _child(args, timeout=300):
     return r.stdout
 
 
-@pytest.mark.parametrize("at", [1, 2, 3, 5])
+@pytest.mark.parametrize("at", [1, 2, 3, 5, 6])
 def test_rccl_local_failure_is_agreed_on_before_the_exchange(at):
     """A rank that fails locally (while preparing, in stage A, allocating its receive buffers, or — 5 —
-    already in a scan below the join) reports it in the status word of the next count all-gather; every rank gives up before the
+    already in a scan below the join) reports it (6, behind the exchange: it is held back for the next join's
+    status word or the end of the plan) in the status word of the next count all-gather; every rank gives up before the
     all-to-all — an error within seconds instead of peers blocked in a collective."""
     out = _child(["inject", str(at)])
     assert "surfaced after" in out and "joins correctly afterwards" in out
@@ -318,7 +319,7 @@ def test_rccl_bring_up_without_its_peers_is_bounded():
     assert "bring-up without its peer failed after" in out
 
 
-@pytest.mark.parametrize("at", [1, 2, 3, 5])
+@pytest.mark.parametrize("at", [1, 2, 3, 5, 6])
 def test_virtual_ranks_local_failure_of_one_rank(at):
     """The same agreement among four virtual ranks of one process: rank 2 fails, the call returns
     its error, nothing hangs, and the context joins correctly afterwards."""
