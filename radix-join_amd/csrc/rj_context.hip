@@ -16,6 +16,7 @@ static int env_int(const char* name, int def) {
 }
 
 void Tuning::from_env() {
+    mall_chunk = env_int("RJ_TUNE_MALL_CHUNK", mall_chunk);
     radix_bits = env_int("RJ_TUNE_RADIX_BITS", radix_bits);
     p1_bits = env_int("RJ_TUNE_P1_BITS", p1_bits);
     fine = env_int("RJ_TUNE_FINE", fine);
@@ -232,6 +233,11 @@ void Context::prewarm() {
     sync();
 }
 
+hipStream_t Context::aux_stream() {
+    if (!aux) RJ_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+    return aux;
+}
+
 hipStream_t Context::upload_stream() {
     if (!copy_stream) RJ_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
     return copy_stream;
@@ -255,6 +261,10 @@ Context::~Context() {
     peers.clear();
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
+    if (aux) {
+        (void)hipStreamSynchronize(aux);
+        (void)hipStreamDestroy(aux);
+    }
     if (copy_stream) {
         (void)hipStreamSynchronize(copy_stream);
         (void)hipStreamDestroy(copy_stream);

@@ -135,6 +135,9 @@ struct PassParams {
     // ... and several input segments may feed ONE output segment (all runs of a local digit):
     // input segment s belongs to output segment s >> oseg_shift, whose bins / cursors it uses
     uint32_t        oseg_shift;
+    // a launch over a sub-range of the segments (a later pass run chunk by chunk): grp_start points at the
+    // sub-range's first entry of the table of ALL segments, whose group numbers start at grp_base
+    uint32_t        grp_base;
     // Composite digit (stage A of a sharded join: owner rank from the TOP hash bits, first local
     // digit from the LOW ones, one pass for both): hi_shift != 0 =>
     //   digit = ((w >> shift) & ((1 << lo_bits) - 1)) | ((w >> hi_shift) << lo_bits)

@@ -453,6 +453,16 @@ class Exec {
                              fine_cursor->as<uint32_t>(), coarse_off->as<uint32_t>(),
                              coarse_cursor->as<uint32_t>(), cx);
         }
+        // RJ_TUNE_MALL_CHUNK: the second pass of a big packed two-pass plan runs chunk by chunk (below)
+        struct Ev2 {
+            hipEvent_t e = nullptr;
+            void       make() { RJ_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
+            ~Ev2() {
+                if (e) (void)hipEventDestroy(e);
+            }
+        } chunk_ev;
+        const bool chunk_second = ctx->tune.mall_chunk > 0 && passes == 2 && !fine && !shape && !ws && !external && P.packed &&
+                                  !packed_side && ctx->tune.xcd_split && n >= (uint64_t)ctx->tune.xcd_min_rows;
         for (uint32_t p = 0; p < passes; ++p) {
             const uint32_t F = 1u << pbits[p];
             PassParams     pp{};
@@ -518,6 +528,54 @@ class Exec {
                     RJ_HIP(hipMemsetAsync(hist->p, 0, (bins << pp.xcd_log2) * 4, ctx->stream));
                     pp.hist = hist->as<uint32_t>();
                     pp.cursor = cursor->as<uint32_t>();
+                    if (p == 1 && chunk_second) {
+                        // ---- histogram / scan / scatter of this pass, `mall_chunk` input segments at a time,
+                        // chunks alternating between the context's two compute streams: the scatter of a
+                        // chunk re-reads what its histogram launch has just pulled through the Infinity
+                        // Cache.  Segments never share bins, cursors or output ranges, so the chunks are
+                        // independent; grids are exact (the segment sizes are on the host by now).
+                        RJ_HIP(hipEventSynchronize(chunk_ev.e));
+                        const uint32_t* hoff = static_cast<const uint32_t*>(ctx->small_pinned());
+                        const uint64_t  gt = (uint64_t)pp.tiles_per_group * PT_TILE;
+                        std::vector<uint32_t> gstart(nseg_in + 1, 0);
+                        for (uint32_t sgi = 0; sgi < nseg_in; ++sgi)
+                            gstart[sgi + 1] = gstart[sgi] + (uint32_t)(((uint64_t)(hoff[sgi + 1] - hoff[sgi]) + gt - 1) / gt);
+                        Ev2 e_in, e_aux;
+                        e_in.make();
+                        e_aux.make();
+                        hipStream_t aux = ctx->aux_stream();
+                        RJ_HIP(hipEventRecord(e_in.e, ctx->stream));  // (behind the previous scatter and the bin memset)
+                        RJ_HIP(hipStreamWaitEvent(aux, e_in.e, 0));
+                        Launch L2 = L;
+                        L2.stream = aux;
+                        const uint32_t CH = (uint32_t)ctx->tune.mall_chunk;
+                        uint32_t       c = 0;
+                        for (uint32_t s0 = 0; s0 < nseg_in; s0 += CH, ++c) {
+                            const uint32_t s1 = std::min(nseg_in, s0 + CH), G = gstart[s1] - gstart[s0];
+                            const Launch& Lc = (c & 1u) ? L2 : L;
+                            PassParams    pc = pp;
+                            pc.nseg = s1 - s0;
+                            pc.seg_off = pp.seg_off + s0;
+                            pc.grp_start = pp.grp_start + s0;
+                            pc.grp_base = gstart[s0];
+                            pc.hist = pp.hist + (size_t)s0 * F;
+                            pc.cursor = pp.cursor + (size_t)s0 * F;
+                            const uint32_t grid = pp.xcd_remap ? ((G + 7u) & ~7u) : G;
+                            if (G) launch_pass_hist_packed(Lc, cur.w[0], pc, grid);
+                            // (empty segments still need their partition offsets)
+                            launch_scan_segments(Lc, pc.hist, pc.seg_off, pc.nseg, F, 0, off->as<uint32_t>() + (size_t)s0 * F, pc.cursor);
+                            if (G) launch_pass_scatter_packed(Lc, cur.w[0], pc, grid, nxt.w[0]);
+                        }
+                        RJ_HIP(hipEventRecord(e_aux.e, aux));
+                        RJ_HIP(hipStreamWaitEvent(ctx->stream, e_aux.e, 0));  // (before any buffer of this pass is reused)
+                        seg_off = off;
+                        nseg = (uint32_t)bins;
+                        shift += pbits[p];
+                        cur = nxt;
+                        cur_is_a = (p % 2 == 0);
+                        nxt = cur_is_a ? wb : wa;
+                        continue;
+                    }
                     if (p == 0 && !ws)
                         launch_pass_hist_src(L, src, KW, pp, n_groups);
                     else if ((mid_side || packed_side) && p > 0)
@@ -533,6 +591,14 @@ class Exec {
                                          n_oseg, F, pp.xcd_log2, off->as<uint32_t>(), pp.cursor);
                 }
                 if (p == 0 && after_offsets) (*after_offsets)(off->as<uint32_t>());
+                // the second pass in chunks needs this pass' partition sizes on the HOST (exact grids per
+                // chunk): they leave now, before the scatter is enqueued, and are read while it runs
+                if (p == 0 && chunk_second) {
+                    if ((bins + 1) * 4 > Context::SMALL_PINNED / 4) throw_fmt(RJ_ERR_DEVICE, "chunked pass: too many segments");
+                    RJ_HIP(hipMemcpyAsync(ctx->small_pinned(), off->p, (bins + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+                    chunk_ev.make();
+                    RJ_HIP(hipEventRecord(chunk_ev.e, ctx->stream));
+                }
                 BufP pt_diag;
                 if (ctx->tune.diag >= 3) {  // phase stamps of the scatter (diagnostic build only)
                     pt_diag = ctx->buf(8 * 8);

@@ -169,6 +169,9 @@ struct Result {
 // Tuning / diagnostic knobs, read from the environment ONCE when the context is created (the
 // plan walk is a hot host path: no getenv per join).
 struct Tuning {
+    int mall_chunk = 0;   // RJ_TUNE_MALL_CHUNK: segments per chunk of the SECOND pass of packed plans — histogram, scan and
+                          // scatter launched chunk by chunk on two streams, so that the scatter re-reads what the
+                          // histogram just read from the 256 MiB Infinity Cache instead of HBM (0 = one launch each)
     int radix_bits = 0;   // RJ_TUNE_RADIX_BITS: total radix bits of every partitioned join (experiments; rj_config.radix_bits wins)
     int p1_bits = 0;      // RJ_TUNE_P1_BITS: radix bits of pass 1 in a two-pass plan (0 = even split)
     int fine = 1;         // RJ_TUNE_FINE: fine (two-digit) histogram for plans <= 2^PT_FINEBITS partitions
@@ -226,6 +229,8 @@ struct Context {
     void*       pinned_up = nullptr;
     size_t      pinned_up_bytes = 0;
     hipStream_t upload_stream();
+    hipStream_t aux = nullptr;   // second compute stream (a later radix pass run chunk by chunk alternates)
+    hipStream_t aux_stream();
     void*       upload_staging(size_t bytes);
     Launch launch() {
         Launch L;

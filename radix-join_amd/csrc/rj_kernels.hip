@@ -916,7 +916,7 @@ __device__ __forceinline__ bool group_range(const PassParams& pp, uint32_t g, ui
         end = (uint32_t)min((uint64_t)pp.n, b + gt);
         return true;
     }
-    const uint32_t G = pp.grp_start[pp.nseg];
+    const uint32_t G = pp.grp_start[pp.nseg] - pp.grp_base;
     if (pp.xcd_remap) {
         const uint32_t per = (G + 7u) >> 3;
         if ((g >> 3) >= per) return false;
@@ -926,13 +926,13 @@ __device__ __forceinline__ bool group_range(const PassParams& pp, uint32_t g, ui
     uint32_t lo = 0, hi = pp.nseg;  // largest s with grp_start[s] <= g
     while (hi - lo > 1) {
         uint32_t mid = (lo + hi) >> 1;
-        if (pp.grp_start[mid] <= g)
+        if (pp.grp_start[mid] - pp.grp_base <= g)
             lo = mid;
         else
             hi = mid;
     }
     seg = lo >> pp.oseg_shift;  // the OUTPUT segment (bins, cursors) input segment `lo` feeds
-    uint32_t gi = g - pp.grp_start[lo];
+    uint32_t gi = g - (pp.grp_start[lo] - pp.grp_base);
     uint64_t b = (uint64_t)pp.seg_off[lo] + (uint64_t)gi * gt;
     begin = (uint32_t)b;
     end = (uint32_t)min((uint64_t)(pp.seg_end ? pp.seg_end[lo] : pp.seg_off[lo + 1]), b + gt);

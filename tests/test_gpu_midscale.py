@@ -30,6 +30,9 @@ _KNOBS = {
     # 12-byte tuples between the passes WITHOUT the side array: the later histogram reads the keys
     # out of the tuples (Aos3KeyLoader)
     "mid3": ({"RJ_TUNE_XCD_MIN_ROWS": "0", "RJ_TUNE_AOS_MID": "3"}, {"radix_bits": 16}),
+    # the second pass of packed two-pass plans chunk by chunk on two streams (RJ_TUNE_MALL_CHUNK: measured
+    # slower at 1 B rows and off by default; 3 segments per chunk here, so that chunks end inside the XCD grid)
+    "chunks": ({"RJ_TUNE_XCD_MIN_ROWS": "0", "RJ_TUNE_MALL_CHUNK": "3"}, {"radix_bits": 16}),
 }
 
 
