@@ -394,8 +394,12 @@ def main():
         # a reported baseline on the host cores, not part of any timed GPU region
         if torch.cuda.device_count() == 0:
             raise SystemExit("bench.py needs a GPU: the HIP path is the product, there is no CPU fallback")
-        cpu = cpu_baseline(args.cpu_sample)
-        cpu["host_cores_available"] = os.cpu_count()
+        try:
+            cpu = cpu_baseline(args.cpu_sample)
+            cpu["host_cores_available"] = os.cpu_count()
+        except Exception as e:  # noqa: BLE001  (the GPU line is still worth having)
+            cpu = {"value": None, "unit": "probe tuples/s", "cores": 0, "kind": "port", "sample": "failed",
+                   "error": f"{type(e).__name__}: {e}"[:300]}
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path is the product, there is no CPU fallback")
     dev_index = local_rank % torch.cuda.device_count()
@@ -432,11 +436,22 @@ def main():
         "roofline": head["roofline"],
     }
     if not args.no_extras:
+        # the extras never take the headline line with them: a failure is recorded in its place
+        def guarded(fn, *a, **kw):
+            try:
+                return fn(*a, **kw)
+            except Exception as e:  # noqa: BLE001
+                return {"error": f"{type(e).__name__}: {e}"[:300]}
+
         extras = {}
         for name, st, wu in (("config2", 10, 2), ("uniform1b", 5, 1)):
             if name == args.workload:
                 continue
-            r, _ = run_single(name, device, dev_index, st, wu, verify=not args.no_verify)
+            got = guarded(run_single, name, device, dev_index, st, wu, verify=not args.no_verify)
+            if isinstance(got, dict):
+                extras[name] = got
+                continue
+            r, _ = got
             rf = r["roofline"] or {}
             extras[name] = {
                 "label": r["label"],
@@ -450,8 +465,8 @@ def main():
                 "kernels_frac": {k: v["frac"] for k, v in (rf.get("kernels") or {}).items()},
             }
         out["configs"] = extras
-        out["plan_ms"] = job_plan_ms(dev_index)
-        out["ingest"] = ingest_ms(dev_index, with_cpu=not args.no_cpu_baseline)
+        out["plan_ms"] = guarded(job_plan_ms, dev_index)
+        out["ingest"] = guarded(ingest_ms, dev_index, with_cpu=not args.no_cpu_baseline)
     if cpu is not None:
         out["cpu_baseline"] = cpu
     print(json.dumps(out))
