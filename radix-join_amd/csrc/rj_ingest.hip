@@ -78,6 +78,21 @@ __device__ __forceinline__ uint32_t csv_next(uint32_t st, uint8_t c) {
     return 1u;
 }
 
+// the bytes [b, e) of the text, 16 at a time: b is a multiple of the segment size and the text starts
+// on an allocation boundary, so the vector loads are aligned (one load instruction per 16 bytes —
+// byte loads, every lane in a line of its own, kept the memory pipeline busy 16 times as long)
+template <class F>
+__device__ __forceinline__ void for_each_byte(const uint8_t* t, uint32_t b, uint32_t e, F&& f) {
+    uint32_t i = b;
+    for (; i + 16 <= e; i += 16) {
+        const uint4    v = *reinterpret_cast<const uint4*>(t + i);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) f(i + k, (uint8_t)(w[k >> 2] >> (8 * (k & 3))));
+    }
+    for (; i < e; ++i) f(i, t[i]);
+}
+
 // transition of a run of bytes: to[s] packed two bits each
 __device__ __forceinline__ uint32_t tr_apply(uint32_t tr, uint32_t s) { return (tr >> (2 * s)) & 3u; }
 __device__ __forceinline__ uint32_t tr_compose(uint32_t first, uint32_t then) {  // then(first(s))
@@ -89,12 +104,11 @@ __global__ __launch_bounds__(256) void k_csv_trans(const uint8_t* t, uint32_t n,
     if (seg >= n_seg) return;
     const uint32_t b = seg * SEG, e = min(n, b + SEG);
     uint32_t       s0 = 0, s1 = 1, s2 = 2;
-    for (uint32_t i = b; i < e; ++i) {
-        const uint8_t c = t[i];
+    for_each_byte(t, b, e, [&](uint32_t, uint8_t c) {
         s0 = csv_next(s0, c);
         s1 = csv_next(s1, c);
         s2 = csv_next(s2, c);
-    }
+    });
     trans[seg] = (uint8_t)(s0 | (s1 << 2) | (s2 << 4));
 }
 
@@ -137,8 +151,7 @@ template <class FC, class FR>
 __device__ __forceinline__ void csv_walk(const uint8_t* t, uint32_t n, uint32_t seg, uint32_t st, FC&& on_comma, FR&& on_rec) {
     const uint32_t b = seg * SEG, e = min(n, b + SEG);
     uint8_t        prev = b ? t[b - 1] : (uint8_t)0;
-    for (uint32_t i = b; i < e; ++i) {
-        const uint8_t c = t[i];
+    for_each_byte(t, b, e, [&](uint32_t i, uint8_t c) {
         if (st == 0) {
             if (c == ',')
                 on_comma(i);
@@ -147,7 +160,7 @@ __device__ __forceinline__ void csv_walk(const uint8_t* t, uint32_t n, uint32_t 
         }
         st = csv_next(st, c);
         prev = c;
-    }
+    });
 }
 
 // per segment: record ends, and the commas behind the last of them (bit 31: the segment has one)
@@ -667,26 +680,38 @@ __global__ __launch_bounds__(256) void k_ing_next_vc(const uint32_t* vx, const u
 struct IngPage {
     uint32_t first, nr, piece;  // piece: 0 = normal page, 1 + k = piece k of the long string in row `first`
 };
-// one thread hops from page start to page start; out == nullptr: count only
-__global__ void k_ing_walk(const uint32_t* nxt, const uint32_t* len /* VARCHAR, else nullptr */, uint32_t n, IngPage* out,
-                           uint32_t* n_pages) {
-    if (blockIdx.x || threadIdx.x) return;
-    uint32_t np = 0;
-    for (uint32_t i = 0; i < n;) {
-        if (len && len[i] != NULL_LEN && len[i] > VC_INLINE_MAX) {
-            const uint32_t k = (len[i] + VC_PIECE - 1) / VC_PIECE;
-            if (out)
-                for (uint32_t s = 0; s < k; ++s) out[np + s] = IngPage{i, 0u, 1u + s};
+// one thread per column hops from page start to page start; out == nullptr: count only
+// the walks of ALL columns in one launch (workgroup c = column c): a hop is a dependent global load,
+// so the walks cost their sum one after the other and their maximum side by side
+struct WalkJob {
+    const uint32_t* nxt;
+    const uint32_t* len;
+    IngPage*        out;
+    uint32_t*       n_pages;
+    uint32_t        n, pad;
+};
+struct WalkJobs {
+    WalkJob j[MAX_ING_COLS];
+};
+__global__ void k_ing_walk_all(WalkJobs jobs) {
+    if (threadIdx.x) return;
+    const WalkJob& w = jobs.j[blockIdx.x];
+    uint32_t       np = 0;
+    for (uint32_t i = 0; i < w.n;) {
+        if (w.len && w.len[i] != NULL_LEN && w.len[i] > VC_INLINE_MAX) {
+            const uint32_t k = (w.len[i] + VC_PIECE - 1) / VC_PIECE;
+            if (w.out)
+                for (uint32_t s = 0; s < k; ++s) w.out[np + s] = IngPage{i, 0u, 1u + s};
             np += k;
             ++i;
             continue;
         }
-        const uint32_t j = nxt[i];
-        if (out) out[np] = IngPage{i, j - i, 0u};
+        const uint32_t j = w.nxt[i];
+        if (w.out) w.out[np] = IngPage{i, j - i, 0u};
         ++np;
         i = j;
     }
-    *n_pages = np;
+    *w.n_pages = np;
 }
 
 // ------------------------------------------------------------------ page writers
@@ -915,7 +940,11 @@ Table* table_from_csv(Context* ctx, const char* text, uint64_t n_bytes, uint64_t
         for (size_t o = 0; o < n_bytes; o += CH, ++k) {
             const size_t m = std::min(CH, (size_t)n_bytes - o);
             if (k >= 2) (void)hipEventSynchronize(ev[k & 1].e);
-            memcpy(stage + (k & 1) * CH, text + o, m);
+            {  // (the host workers share the copy: one thread moves ~10 GB/s, the link 50)
+                uint8_t*    dst = stage + (k & 1) * CH;
+                const char* srcp = text + o;
+                parallel_for(m, (size_t)1 << 20, [&](size_t b0, size_t e0) { memcpy(dst + b0, srcp + b0, e0 - b0); });
+            }
             RJ_HIP(hipMemcpyAsync(dtext->as<uint8_t>() + o, stage + (k & 1) * CH, m, hipMemcpyHostToDevice, ctx->stream));
             RJ_HIP(hipEventRecord(ev[k & 1].e, ctx->stream));
         }
@@ -1106,69 +1135,89 @@ Table* table_from_csv(Context* ctx, const char* text, uint64_t n_bytes, uint64_t
     const uint32_t n_out = read_u32(ctx, excl->as<uint32_t>() + n_rows);
     tab->num_rows = n_out;
     if (!n_out) return tab.release();
-    // ---- pages, column by column (from_inner_to_column, build_table.cpp:94-119)
+    // ---- pages (from_inner_to_column, build_table.cpp:94-119): per column the compacted values, the
+    // "first row of the next page" of every row, then ONE launch that walks all columns' page starts
+    // (count), one that records them, and a page writer per column
     const uint32_t ogrid = (n_out + 255) / 256;
     std::vector<const void*> dev_pages(n_cols, nullptr);
     std::vector<uint64_t>    n_pages(n_cols, 0);
     std::vector<BufP>        page_bufs(n_cols);
+    struct ColWork {
+        BufP vx, o_valid, nxt, o_values, o_row, o_len, cx, plist;
+    };
+    std::vector<ColWork> work(n_cols);
+    BufP                 np_dev = ctx->buf((size_t)n_cols * 4);
+    std::unique_ptr<WalkJobs> jobs(new WalkJobs());
+    memset(jobs.get(), 0, sizeof(WalkJobs));
     for (uint64_t c = 0; c < n_cols; ++c) {
-        BufP vx = ctx->buf(((size_t)n_out + 1) * 4), o_valid = ctx->buf((size_t)n_out * 4), nxt = ctx->buf((size_t)n_out * 4);
-        BufP np_dev = ctx->buf(16), plist;
+        ColWork& w = work[c];
+        w.vx = ctx->buf(((size_t)n_out + 1) * 4);
+        w.o_valid = ctx->buf((size_t)n_out * 4);
+        w.nxt = ctx->buf((size_t)n_out * 4);
         if (col_type[c] != RJ_VARCHAR) {
             const int W = col_type[c] == RJ_INT32 ? 4 : 8;
-            BufP      o_values = ctx->buf((size_t)n_out * W);
-            RJ_ILAUNCH(L, "ingest_pages", k_ing_compact_fixed, rgrid, 256, sel->as<uint32_t>(), excl->as<uint32_t>(), n_rows, W,
-                       typed[c].values->as<uint8_t>(), typed[c].valid->as<uint8_t>(), o_values->as<uint8_t>(),
-                       o_valid->as<uint32_t>());
-            RJ_HIP(hipMemcpyAsync(vx->p, o_valid->p, (size_t)n_out * 4, hipMemcpyDeviceToDevice, ctx->stream));
-            device_scan(ctx, L, vx->as<uint32_t>(), n_out, vx->as<uint32_t>() + n_out);
-            RJ_ILAUNCH(L, "ingest_pages", k_ing_next_fixed, ogrid, 256, vx->as<uint32_t>(), o_valid->as<uint32_t>(), n_out,
-                       (uint32_t)W, nxt->as<uint32_t>());
-            RJ_ILAUNCH(L, "ingest_pages", k_ing_walk, 1, 64, nxt->as<uint32_t>(), (const uint32_t*)nullptr, n_out, (IngPage*)nullptr,
-                       np_dev->as<uint32_t>());
-            const uint32_t np = read_u32(ctx, np_dev->as<uint32_t>());
-            plist = ctx->buf((size_t)np * sizeof(IngPage));
-            RJ_ILAUNCH(L, "ingest_pages", k_ing_walk, 1, 64, nxt->as<uint32_t>(), (const uint32_t*)nullptr, n_out,
-                       plist->as<IngPage>(), np_dev->as<uint32_t>());
+            w.o_values = ctx->buf((size_t)n_out * W);
+            RJ_ILAUNCH(L, "ingest_compact", k_ing_compact_fixed, rgrid, 256, sel->as<uint32_t>(), excl->as<uint32_t>(), n_rows, W,
+                       typed[c].values->as<uint8_t>(), typed[c].valid->as<uint8_t>(), w.o_values->as<uint8_t>(),
+                       w.o_valid->as<uint32_t>());
+            RJ_HIP(hipMemcpyAsync(w.vx->p, w.o_valid->p, (size_t)n_out * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            device_scan(ctx, L, w.vx->as<uint32_t>(), n_out, w.vx->as<uint32_t>() + n_out);
+            RJ_ILAUNCH(L, "ingest_next", k_ing_next_fixed, ogrid, 256, w.vx->as<uint32_t>(), w.o_valid->as<uint32_t>(), n_out,
+                       (uint32_t)W, w.nxt->as<uint32_t>());
+        } else {
+            w.o_row = ctx->buf((size_t)n_out * 4);
+            w.o_len = ctx->buf((size_t)n_out * 4);
+            w.cx = ctx->buf(((size_t)n_out + 1) * 4);
+            RJ_ILAUNCH(L, "ingest_compact", k_ing_compact_vc, rgrid, 256, sel->as<uint32_t>(), excl->as<uint32_t>(), n_rows,
+                       typed[c].len->as<uint32_t>(), w.o_row->as<uint32_t>(), w.o_len->as<uint32_t>(), w.vx->as<uint32_t>(),
+                       w.cx->as<uint32_t>());
+            device_scan(ctx, L, w.vx->as<uint32_t>(), n_out, w.vx->as<uint32_t>() + n_out);
+            device_scan(ctx, L, w.cx->as<uint32_t>(), n_out, w.cx->as<uint32_t>() + n_out);
+            RJ_ILAUNCH(L, "ingest_next", k_ing_next_vc, ogrid, 256, w.vx->as<uint32_t>(), w.cx->as<uint32_t>(), n_out,
+                       w.nxt->as<uint32_t>());
+        }
+        jobs->j[c] = WalkJob{w.nxt->as<uint32_t>(), w.o_len ? w.o_len->as<uint32_t>() : nullptr, nullptr,
+                             np_dev->as<uint32_t>() + c, n_out, 0u};
+    }
+    RJ_ILAUNCH(L, "ingest_walk", k_ing_walk_all, (uint32_t)n_cols, 64, *jobs);
+    std::vector<uint32_t> np_host(n_cols, 0);
+    RJ_HIP(hipMemcpyAsync(np_host.data(), np_dev->p, (size_t)n_cols * 4, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->sync();
+    for (uint64_t c = 0; c < n_cols; ++c) {
+        work[c].plist = ctx->buf((size_t)std::max<uint32_t>(np_host[c], 1u) * sizeof(IngPage));
+        jobs->j[c].out = work[c].plist->as<IngPage>();
+    }
+    RJ_ILAUNCH(L, "ingest_walk", k_ing_walk_all, (uint32_t)n_cols, 64, *jobs);
+    std::vector<BufP> vpages(n_cols);
+    for (uint64_t c = 0; c < n_cols; ++c) {
+        ColWork&       w = work[c];
+        const uint32_t np = np_host[c];
+        if (!np) continue;  // (cannot happen: n_out > 0 rows make at least one page)
+        if (col_type[c] != RJ_VARCHAR) {
             page_bufs[c] = ctx->buf((size_t)np * PAGE_BYTES);
-            if (W == 4)
-                RJ_ILAUNCH(L, "ingest_pages", (k_ing_pages_fixed<4>), np, 256, plist->as<IngPage>(), o_values->as<uint8_t>(),
-                           o_valid->as<uint32_t>(), page_bufs[c]->as<uint8_t>());
+            if (col_type[c] == RJ_INT32)
+                RJ_ILAUNCH(L, "ingest_pages", (k_ing_pages_fixed<4>), np, 256, w.plist->as<IngPage>(), w.o_values->as<uint8_t>(),
+                           w.o_valid->as<uint32_t>(), page_bufs[c]->as<uint8_t>());
             else
-                RJ_ILAUNCH(L, "ingest_pages", (k_ing_pages_fixed<8>), np, 256, plist->as<IngPage>(), o_values->as<uint8_t>(),
-                           o_valid->as<uint32_t>(), page_bufs[c]->as<uint8_t>());
+                RJ_ILAUNCH(L, "ingest_pages", (k_ing_pages_fixed<8>), np, 256, w.plist->as<IngPage>(), w.o_values->as<uint8_t>(),
+                           w.o_valid->as<uint32_t>(), page_bufs[c]->as<uint8_t>());
             n_pages[c] = np;
             dev_pages[c] = page_bufs[c]->p;
-            ctx->sync();  // (o_values & co. go back to the block cache at the end of this iteration)
         } else {
-            BufP o_row = ctx->buf((size_t)n_out * 4), o_len = ctx->buf((size_t)n_out * 4), cx = ctx->buf(((size_t)n_out + 1) * 4);
-            RJ_ILAUNCH(L, "ingest_pages", k_ing_compact_vc, rgrid, 256, sel->as<uint32_t>(), excl->as<uint32_t>(), n_rows,
-                       typed[c].len->as<uint32_t>(), o_row->as<uint32_t>(), o_len->as<uint32_t>(), vx->as<uint32_t>(),
-                       cx->as<uint32_t>());
-            device_scan(ctx, L, vx->as<uint32_t>(), n_out, vx->as<uint32_t>() + n_out);
-            device_scan(ctx, L, cx->as<uint32_t>(), n_out, cx->as<uint32_t>() + n_out);
-            RJ_ILAUNCH(L, "ingest_pages", k_ing_next_vc, ogrid, 256, vx->as<uint32_t>(), cx->as<uint32_t>(), n_out,
-                       nxt->as<uint32_t>());
-            RJ_ILAUNCH(L, "ingest_pages", k_ing_walk, 1, 64, nxt->as<uint32_t>(), o_len->as<uint32_t>(), n_out, (IngPage*)nullptr,
-                       np_dev->as<uint32_t>());
-            const uint32_t np = read_u32(ctx, np_dev->as<uint32_t>());
-            plist = ctx->buf((size_t)np * sizeof(IngPage));
-            RJ_ILAUNCH(L, "ingest_pages", k_ing_walk, 1, 64, nxt->as<uint32_t>(), o_len->as<uint32_t>(), n_out, plist->as<IngPage>(),
-                       np_dev->as<uint32_t>());
-            BufP vpages = ctx->buf((size_t)np * PAGE_BYTES);
-            RJ_ILAUNCH(L, "ingest_pages", k_ing_pages_vc, np, 256, plist->as<IngPage>(), t, fend->as<uint32_t>(), (uint32_t)n_cols,
-                       (uint32_t)c, o_row->as<uint32_t>(), o_len->as<uint32_t>(), vpages->as<uint8_t>());
+            vpages[c] = ctx->buf((size_t)np * PAGE_BYTES);
+            RJ_ILAUNCH(L, "ingest_pages", k_ing_pages_vc, np, 256, w.plist->as<IngPage>(), t, fend->as<uint32_t>(), (uint32_t)n_cols,
+                       (uint32_t)c, w.o_row->as<uint32_t>(), w.o_len->as<uint32_t>(), vpages[c]->as<uint8_t>());
             // VARCHAR pages live on the host side of a resident table (the executor resolves strings
             // at the root, rj_varchar*.{cpp,hip})
             TableColumn& tc = tab->cols[c];
             tc.n_pages = np;
             tc.host_pages.resize((size_t)np * PAGE_BYTES);
-            RJ_HIP(hipMemcpyAsync(tc.host_pages.data(), vpages->p, (size_t)np * PAGE_BYTES, hipMemcpyDeviceToHost, ctx->stream));
-            ctx->sync();
+            RJ_HIP(hipMemcpyAsync(tc.host_pages.data(), vpages[c]->p, (size_t)np * PAGE_BYTES, hipMemcpyDeviceToHost, ctx->stream));
             tc.vc_pages.resize(np);
             for (uint32_t p = 0; p < np; ++p) tc.vc_pages[p] = tc.host_pages.data() + (size_t)p * PAGE_BYTES;
         }
     }
+    ctx->sync();  // (the columns' work buffers go back to the block cache when this function returns)
     // fixed-width columns: adopt the page images (regularity, row counts: rj_table.hip)
     std::unique_ptr<Table> adopted(table_adopt(ctx, n_out, n_cols, col_type, dev_pages.data(), n_pages.data()));
     for (uint64_t c = 0; c < n_cols; ++c) {

@@ -37,7 +37,7 @@ del parts
 print(f"{n} rows, {len(text) / 1e6:.0f} MB of text (written in {time.time() - t0:.0f} s)", flush=True)
 types = [1, 0, 0, 3, 0, 2]  # INT64, INT32, INT32, VARCHAR, INT32, FP64
 filt = [("GT", 2, 1_000_000), ("IS_NOT_NULL", 4), ("AND",), ("LIKE", 3, b"(%)"), ("OR",)]
-ctx = capi.Context()
+ctx = capi.Context(profile=2 if os.environ.get("RJ_INGEST_PROFILE") == "1" else False)
 for k in range(2):
     t0 = time.time()
     t = ctx.from_csv(text, types, filt)
@@ -45,6 +45,10 @@ for k in range(2):
     print(f"device: {dt * 1e3:.0f} ms = {len(text) / dt / 1e9:.2f} GB/s of text", flush=True)
     if k == 0:
         t.release()
+        if os.environ.get("RJ_INGEST_PROFILE") == "1":
+            ctx.profile_reset()
+if os.environ.get("RJ_INGEST_PROFILE") == "1":
+    print("   " + "  ".join("%s=%.2f(%d)" % (k["name"], k["total_ms"], k["launches"]) for k in ctx.profile()), flush=True)
 got = ctx.table_to_host(t)
 t.release()
 t0 = time.time()
