@@ -8,7 +8,7 @@
 //   Comparison / LogicalOperation   src/statement.cpp:8-135,186-201 (over include/inner_column.h:
 //                                   170-324, :372-562 for strings; LIKE: statement.h:118-161) k_ing_filter
 //   from_inner_to_column +          src/build_table.cpp:94-119,
-//   ColumnInserter<T>, <string>     include/plan.h:151-335        k_ing_next_*, k_ing_walk_*,
+//   ColumnInserter<T>, <string>     include/plan.h:151-335        k_ing_next_*, k_hop_*, k_ing_walk_all, k_ing_expand,
 //                                                                 k_ing_pages_fixed / _varchar
 //
 // The parser is a three-state machine — unquoted / quoted / quoted with an active backslash
@@ -22,8 +22,9 @@
 //
 // The page-fill rules are sequential in the reference; here the first row of the NEXT page is
 // computed for every row independently — "row j does not fit a page that starts at row i" is a
-// monotone predicate over prefix sums (values, characters), found by binary search — and one
-// thread then hops from page start to page start (a few thousand hops per million rows).  The
+// monotone predicate over prefix sums (values, characters), found by binary search — and the chain
+// of page starts is then shortened by pointer jumping, walked 32 hops at a time by one thread per
+// column and filled in by one thread per 32-hop stretch (k_hop_*, k_ing_walk_all, k_ing_expand).  The
 // pages written are the ones ColumnInserter produces, byte for byte where the reference defines
 // the bytes.
 #include <hip/hip_ext.h>
@@ -680,38 +681,71 @@ __global__ __launch_bounds__(256) void k_ing_next_vc(const uint32_t* vx, const u
 struct IngPage {
     uint32_t first, nr, piece;  // piece: 0 = normal page, 1 + k = piece k of the long string in row `first`
 };
-// one thread per column hops from page start to page start; out == nullptr: count only
-// the walks of ALL columns in one launch (workgroup c = column c): a hop is a dependent global load,
-// so the walks cost their sum one after the other and their maximum side by side
+// From page start to page start.  The chain 0 -> next(0) -> next(next(0)) ... is sequential (a hop is a
+// dependent load), so it is shortened first: five rounds of pointer jumping (hop <- hop o hop, weights
+// added; `next` is monotone, so the gathers of a round read almost in order) leave every row with its
+// 32nd successor and the pages in between.  One thread per column then walks the 32-hop chain — all
+// columns in one launch — and notes where every super-hop starts and how many pages lie before it;
+// the hops inside each super-hop are re-walked by one thread per super-hop, in parallel, writing the
+// page list.  A long string (VARCHAR) is a hop to the next row that weighs its number of pieces.
+constexpr int HOP_ROUNDS = 5;
+__device__ __forceinline__ uint2 hop0(const uint32_t* nxt, const uint32_t* len, uint32_t i) {
+    if (len) {
+        const uint32_t l = len[i];
+        if (l != NULL_LEN && l > VC_INLINE_MAX) return make_uint2(i + 1u, (l + VC_PIECE - 1) / VC_PIECE);
+    }
+    return make_uint2(nxt[i], 1u);
+}
+__global__ __launch_bounds__(256) void k_hop_init(const uint32_t* nxt, const uint32_t* len, uint32_t n, uint2* hw) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    hw[i] = i < n ? hop0(nxt, len, i) : make_uint2(n, 0u);
+}
+__global__ __launch_bounds__(256) void k_hop_double(const uint2* in, uint32_t n, uint2* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    const uint2 a = in[i], b = in[a.x];
+    out[i] = make_uint2(b.x, a.y + b.y);
+}
 struct WalkJob {
-    const uint32_t* nxt;
-    const uint32_t* len;
-    IngPage*        out;
-    uint32_t*       n_pages;
-    uint32_t        n, pad;
+    const uint2* hw;       // {32nd successor, pages up to it} of every row
+    uint2*       super;    // out: {row, pages before it} of every super-hop start
+    uint32_t*    counts;   // out: [0] = super-hops, [1] = pages
+    uint32_t     n, pad;
 };
 struct WalkJobs {
     WalkJob j[MAX_ING_COLS];
 };
-__global__ void k_ing_walk_all(WalkJobs jobs) {
+__global__ void k_ing_walk_all(WalkJobs jobs) {  // workgroup c = column c
     if (threadIdx.x) return;
     const WalkJob& w = jobs.j[blockIdx.x];
-    uint32_t       np = 0;
+    uint32_t       ns = 0, pages = 0;
     for (uint32_t i = 0; i < w.n;) {
-        if (w.len && w.len[i] != NULL_LEN && w.len[i] > VC_INLINE_MAX) {
-            const uint32_t k = (w.len[i] + VC_PIECE - 1) / VC_PIECE;
-            if (w.out)
-                for (uint32_t s = 0; s < k; ++s) w.out[np + s] = IngPage{i, 0u, 1u + s};
-            np += k;
-            ++i;
-            continue;
-        }
-        const uint32_t j = w.nxt[i];
-        if (w.out) w.out[np] = IngPage{i, j - i, 0u};
-        ++np;
-        i = j;
+        w.super[ns++] = make_uint2(i, pages);
+        const uint2 a = w.hw[i];
+        pages += a.y;
+        i = a.x;
     }
-    *w.n_pages = np;
+    w.counts[0] = ns;
+    w.counts[1] = pages;
+}
+__global__ __launch_bounds__(256) void k_ing_expand(const uint32_t* nxt, const uint32_t* len, uint32_t n, const uint2* super,
+                                                    uint32_t ns, IngPage* out) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ns) return;
+    const uint2    s = super[j];
+    const uint32_t end = j + 1 < ns ? super[j + 1].x : n;
+    uint32_t       np = s.y;
+    for (uint32_t i = s.x; i < end;) {
+        const uint2 h = hop0(nxt, len, i);
+        if (h.x == i + 1u && len && len[i] != NULL_LEN && len[i] > VC_INLINE_MAX) {
+            for (uint32_t p = 0; p < h.y; ++p) out[np + p] = IngPage{i, 0u, 1u + p};
+        } else {
+            out[np] = IngPage{i, h.x - i, 0u};
+        }
+        np += h.y;
+        i = h.x;
+    }
 }
 
 // ------------------------------------------------------------------ page writers
@@ -1136,17 +1170,17 @@ Table* table_from_csv(Context* ctx, const char* text, uint64_t n_bytes, uint64_t
     tab->num_rows = n_out;
     if (!n_out) return tab.release();
     // ---- pages (from_inner_to_column, build_table.cpp:94-119): per column the compacted values, the
-    // "first row of the next page" of every row, then ONE launch that walks all columns' page starts
-    // (count), one that records them, and a page writer per column
+    // "first row of the next page" of every row, the page starts (pointer jumping, then ONE launch that
+    // walks all columns' 32-hop chains, then one thread per super-hop), and a page writer per column
     const uint32_t ogrid = (n_out + 255) / 256;
     std::vector<const void*> dev_pages(n_cols, nullptr);
     std::vector<uint64_t>    n_pages(n_cols, 0);
     std::vector<BufP>        page_bufs(n_cols);
     struct ColWork {
-        BufP vx, o_valid, nxt, o_values, o_row, o_len, cx, plist;
+        BufP vx, o_valid, nxt, o_values, o_row, o_len, cx, plist, hw_a, hw_b, super;
     };
     std::vector<ColWork> work(n_cols);
-    BufP                 np_dev = ctx->buf((size_t)n_cols * 4);
+    BufP                 np_dev = ctx->buf((size_t)n_cols * 8);  // per column: super-hops, pages
     std::unique_ptr<WalkJobs> jobs(new WalkJobs());
     memset(jobs.get(), 0, sizeof(WalkJobs));
     for (uint64_t c = 0; c < n_cols; ++c) {
@@ -1176,22 +1210,34 @@ Table* table_from_csv(Context* ctx, const char* text, uint64_t n_bytes, uint64_t
             RJ_ILAUNCH(L, "ingest_next", k_ing_next_vc, ogrid, 256, w.vx->as<uint32_t>(), w.cx->as<uint32_t>(), n_out,
                        w.nxt->as<uint32_t>());
         }
-        jobs->j[c] = WalkJob{w.nxt->as<uint32_t>(), w.o_len ? w.o_len->as<uint32_t>() : nullptr, nullptr,
-                             np_dev->as<uint32_t>() + c, n_out, 0u};
+        // the 32-hop chain of this column (pointer jumping, ping-pong between two arrays)
+        w.hw_a = ctx->buf(((size_t)n_out + 1) * 8);
+        w.hw_b = ctx->buf(((size_t)n_out + 1) * 8);
+        const uint32_t* lenp = w.o_len ? w.o_len->as<uint32_t>() : nullptr;
+        RJ_ILAUNCH(L, "ingest_walk", k_hop_init, (n_out + 256) / 256, 256, w.nxt->as<uint32_t>(), lenp, n_out, w.hw_a->as<uint2>());
+        for (int r = 0; r < HOP_ROUNDS; ++r) {
+            RJ_ILAUNCH(L, "ingest_walk", k_hop_double, (n_out + 256) / 256, 256, w.hw_a->as<uint2>(), n_out, w.hw_b->as<uint2>());
+            std::swap(w.hw_a, w.hw_b);
+        }
+        w.super = ctx->buf(((size_t)n_out / (1u << HOP_ROUNDS) + 2) * 8);
+        jobs->j[c] = WalkJob{w.hw_a->as<uint2>(), w.super->as<uint2>(), np_dev->as<uint32_t>() + 2 * c, n_out, 0u};
     }
     RJ_ILAUNCH(L, "ingest_walk", k_ing_walk_all, (uint32_t)n_cols, 64, *jobs);
-    std::vector<uint32_t> np_host(n_cols, 0);
-    RJ_HIP(hipMemcpyAsync(np_host.data(), np_dev->p, (size_t)n_cols * 4, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<uint32_t> np_host(2 * n_cols, 0);
+    RJ_HIP(hipMemcpyAsync(np_host.data(), np_dev->p, (size_t)n_cols * 8, hipMemcpyDeviceToHost, ctx->stream));
     ctx->sync();
     for (uint64_t c = 0; c < n_cols; ++c) {
-        work[c].plist = ctx->buf((size_t)std::max<uint32_t>(np_host[c], 1u) * sizeof(IngPage));
-        jobs->j[c].out = work[c].plist->as<IngPage>();
+        ColWork&       w = work[c];
+        const uint32_t ns = np_host[2 * c], np = np_host[2 * c + 1];
+        w.plist = ctx->buf((size_t)std::max<uint32_t>(np, 1u) * sizeof(IngPage));
+        if (ns)
+            RJ_ILAUNCH(L, "ingest_walk", k_ing_expand, (ns + 255) / 256, 256, w.nxt->as<uint32_t>(),
+                       w.o_len ? w.o_len->as<uint32_t>() : nullptr, n_out, w.super->as<uint2>(), ns, w.plist->as<IngPage>());
     }
-    RJ_ILAUNCH(L, "ingest_walk", k_ing_walk_all, (uint32_t)n_cols, 64, *jobs);
     std::vector<BufP> vpages(n_cols);
     for (uint64_t c = 0; c < n_cols; ++c) {
         ColWork&       w = work[c];
-        const uint32_t np = np_host[c];
+        const uint32_t np = np_host[2 * c + 1];
         if (!np) continue;  // (cannot happen: n_out > 0 rows make at least one page)
         if (col_type[c] != RJ_VARCHAR) {
             page_bufs[c] = ctx->buf((size_t)np * PAGE_BYTES);
