@@ -101,3 +101,21 @@ def test_plan_shardable_is_decided_from_the_plan_alone():
     c = p.new_scan_node(2, [(0, i32), (1, i64)])
     p.root = p.new_join_node(False, j1, c, 1, 0, [(0, i32), (3, i64), (1, i32)])
     assert capi.plan_shardable(p)[0]
+
+
+def test_every_environment_switch_is_documented():
+    """every RJ_* variable the library or the shim reads appears in INTEGRATION.md's table"""
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = set()
+    for sub in ("radix-join_amd/csrc", "radix-join_amd/host"):
+        d = os.path.join(root, sub)
+        for fn in os.listdir(d):
+            if fn.endswith((".hip", ".cpp", ".hpp")):
+                names |= set(re.findall(r'(?:env_int|getenv)\("(RJ_[A-Z0-9_]+)"', open(os.path.join(d, fn)).read()))
+    assert len(names) > 20
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    missing = sorted(n for n in names if n not in doc)
+    assert not missing, missing
