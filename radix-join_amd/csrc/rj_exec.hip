@@ -1240,9 +1240,11 @@ class Exec {
             varchar_dir_build(tc.vc_pages.data(), tc.vc_pages.size(), t->num_rows, it->second);
         }
         const uint32_t npg = (uint32_t)tc.vc_pages.size();
-        if (!tc.vc_dev) {
+        if (!tc.vc_dev) {  // (a table ingested on the device brings its pages along: rj_ingest.hip)
             tc.vc_dev = ctx->buf(std::max<uint64_t>(npg, 1) * PAGE_BYTES);
             upload_host_pages(ctx, tc.vc_pages.data(), npg, tc.vc_dev->as<uint8_t>());
+        }
+        if (!tc.vc_dev_dir) {
             std::vector<uint32_t> dir32(it->second.begin(), it->second.end());
             tc.vc_dev_dir = ctx->buf(dir32.size() * 4);
             RJ_HIP(hipMemcpyAsync(tc.vc_dev_dir->p, dir32.data(), dir32.size() * 4, hipMemcpyHostToDevice,

@@ -1261,6 +1261,9 @@ Table* table_from_csv(Context* ctx, const char* text, uint64_t n_bytes, uint64_t
             RJ_HIP(hipMemcpyAsync(tc.host_pages.data(), vpages[c]->p, (size_t)np * PAGE_BYTES, hipMemcpyDeviceToHost, ctx->stream));
             tc.vc_pages.resize(np);
             for (uint32_t p = 0; p < np; ++p) tc.vc_pages[p] = tc.host_pages.data() + (size_t)p * PAGE_BYTES;
+            // ... and stay in HBM too: the device VARCHAR paths (large root results, VARCHAR join keys)
+            // then upload nothing for this column
+            tc.vc_dev = vpages[c];
         }
     }
     ctx->sync();  // (the columns' work buffers go back to the block cache when this function returns)

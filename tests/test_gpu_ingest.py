@@ -154,10 +154,33 @@ def test_like_on_the_device(ctx):
     assert e.value.code == 5
 
 
-def test_join_over_tables_ingested_on_the_device(ctx):
+@pytest.fixture(params=["host_varchar", "device_varchar"])
+def jctx(request):
+    """two contexts: VARCHAR root columns resolved on the host (small results), and with the device
+    path forced (RJ_TUNE_VARCHAR_DEV=1) — which reads the VARCHAR pages the ingest left in HBM"""
+    import os
+
+    old = os.environ.get("RJ_TUNE_VARCHAR_DEV")
+    if request.param == "device_varchar":
+        os.environ["RJ_TUNE_VARCHAR_DEV"] = "1"
+    try:
+        c = capi.Context()
+    finally:
+        if request.param == "device_varchar":
+            if old is None:
+                del os.environ["RJ_TUNE_VARCHAR_DEV"]
+            else:
+                os.environ["RJ_TUNE_VARCHAR_DEV"] = old
+    yield c
+    capi.destroy_context(c)
+
+
+def test_join_over_tables_ingested_on_the_device(jctx):
     """title-like and cast-like tables arrive as CSV text, are filtered and packed on the device, and
-    the resident tables go straight into rj_execute_resident: nothing is uploaded at execute() time.
+    the resident tables go straight into rj_execute_resident: nothing is uploaded at execute() time
+    (the VARCHAR pages, too, stay where the ingest wrote them).
     Checked against the oracle end to end (its own from_csv, then its execute)."""
+    ctx = jctx
     rng = np.random.default_rng(8)
     nt, nc = 60_000, 250_000
     trows = [(int(i), (b"title %d" % i) if i % 11 else None, int(rng.integers(1900, 2025)) if i % 7 else None) for i in rng.permutation(nt)]
