@@ -232,8 +232,28 @@ def job_plan_ms(dev_index, queries=("1a", "13d", "10c"), repeat=3):
             rows_out = tbl.num_rows
             res.free()
         del keep
+        # the same plan over RESIDENT inputs (what a harness that ingests on the device gets,
+        # rj_table_from_csv -> rj_execute_resident): no PCIe upload inside execute(), result pages
+        # still fetched to the host
+        resident_ms = None
+        try:
+            up = [ctx.upload(t) for t in plan.inputs]
+            rt = []
+            for _ in range(repeat + 1):
+                t0 = time.perf_counter()
+                r = ctx.execute_resident(plan, up, keep_on_device=False)
+                tbl2 = r.to_table()
+                rt.append((time.perf_counter() - t0) * 1e3)
+                r.free()
+            assert tbl2.num_rows == rows_out
+            resident_ms = min(rt[1:])
+            for u in up:
+                u.release()
+        except Exception as e:  # noqa: BLE001
+            resident_ms = f"{type(e).__name__}: {e}"[:200]
         out[f"job/{name}"] = {
             "ms": min(times[1:]),
+            "ms_resident_inputs": resident_ms,
             "ms_first_call": times[0],
             "joins": sum(1 for nd in plan.nodes if isinstance(nd.data, pl.JoinNode)),
             "input_rows": int(sum(t.num_rows for t in plan.inputs)),
