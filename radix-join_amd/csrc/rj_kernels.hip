@@ -1122,6 +1122,9 @@ __global__ __launch_bounds__(PT_MAXF) void k_scan_fine(const uint32_t* fine, uin
 // step (profiles/r03_h_scatter_tile_prefetch_ab.log): the kernels are bound by the memory system's
 // mix of reads and partial-line writes, not by a CU's load latency, and a burst of loads next to
 // the copy-out's stores only gets in their way.  Off; -DRJ_PT_PIPELINE=1 builds it for A/B.
+#ifndef RJ_PT_EXTRA_LOOKUP
+#define RJ_PT_EXTRA_LOOKUP 0
+#endif
 #ifndef RJ_PT_PIPELINE
 #define RJ_PT_PIPELINE 0
 #endif
@@ -1157,6 +1160,18 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassPara
     // Thread d owns digit d's write cursor in a REGISTER: the reservation's round trip is
     // not waited for until the first tile has been loaded and ranked.
     uint32_t run = 0;  // thread d: where digit d's run of the current tile starts in the output
+#if RJ_PT_EXTRA_LOOKUP
+    uint32_t lookup = 0;
+#define RJ_PT_USE_LOOKUP()                  \
+    do {                                    \
+        asm volatile("" : "+v"(lookup));    \
+        run += lookup & 0u;                 \
+    } while (0)
+#else
+#define RJ_PT_USE_LOOKUP() \
+    do {                   \
+    } while (0)
+#endif
 #if RJ_PT_DIAG
     unsigned long long diag_t = pp.diag ? __builtin_amdgcn_s_memtime() : 0ull;
 #endif
@@ -1197,9 +1212,19 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassPara
         // Thread d reserves digit d's range of this tile with one global atomic; its round
         // trip is not waited for until word 0 has been staged.
         uint32_t c = threadIdx.x < F ? s_cnt[threadIdx.x] : 0u;
-        if (c)
+        if (c) {
             run = atomicAdd(&pp.cursor[(((size_t)seg * F + threadIdx.x) << pp.xcd_log2) |
                                        (blockIdx.x & ((1u << pp.xcd_log2) - 1u))], c);
+#if RJ_PT_EXTRA_LOOKUP
+            // (experiment: what a SECOND dependent global round trip per digit and tile would cost — the
+            // chunk-table lookup of a first pass that reserves from chunk lists instead of a histogram's
+            // exact ranges; reads a word of the (by now read-only) bin totals at an index that depends on the
+            // reservation and folds nothing into it.  Reading the cursor array itself, which every
+            // workgroup's atomics keep hot, tripled the first scatter: a chunk table must not share lines
+            // with the cursors)
+            lookup = __builtin_nontemporal_load(&pp.hist[((size_t)(run >> 16) % ((size_t)F << pp.xcd_log2))]);
+#endif
+        }
         uint32_t total;
         uint32_t ex = block_excl_scan(c, s_wsum, total);
         if (threadIdx.x < F) s_base[threadIdx.x] = ex;
@@ -1219,6 +1244,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassPara
             constexpr uint32_t HALF = PT_TILE / 2;
             uint2* const       s_p = s_stage2;                                      // [HALF] carries
             uint32_t* const    s_k = reinterpret_cast<uint32_t*>(s_stage2 + HALF);  // [HALF] keys
+            RJ_PT_USE_LOOKUP();
             if (threadIdx.x < F) s_delta[threadIdx.x] = run - ex;  // global index = delta + sorted position
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -1265,6 +1291,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassPara
 #pragma unroll
         for (int j = 0; j < PT_ITEMS; ++j)
             if (dr[j] != 0xffffffffu) s_stage[dr[j]] = w[j][0];
+        RJ_PT_USE_LOOKUP();
         if (threadIdx.x < F) s_delta[threadIdx.x] = run - ex;  // global index = delta + LDS position
         lds_barrier();
         RJ_PT_STAMP(4);  // word 0 staged
