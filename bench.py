@@ -406,8 +406,9 @@ def main():
     # RJ_BENCH_FORCE_DIST=1: run the sharded path at world size 1 (rehearsal on a one-GPU box,
     # under `python -m torch.distributed.run --nproc-per-node 1`)
     distributed = world > 1 or os.environ.get("RJ_BENCH_FORCE_DIST") == "1"
-    if args.gpus != world and distributed:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus != world and (distributed or args.gpus > 1):
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 as `python -m torch.distributed.run "
+                         f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...`")
     cpu = None
     if not distributed and not args.no_cpu_baseline:
         # first, while this process has not touched the GPU yet (the workers are forked); it is
