@@ -951,6 +951,10 @@ struct loader_needs_begin<L, std::enable_if_t<L::kNeedsBegin>> : std::true_type 
 template <class Loader>
 __global__ __launch_bounds__(PT_THREADS) void k_pass_hist(Loader ld, PassParams pp) {
     __shared__ uint32_t s_h[PT_MAXF];
+#if RJ_PT_HOT_PROBE
+    __shared__ uint32_t s_hot[4096];
+    for (uint32_t d = threadIdx.x; d < 4096; d += PT_THREADS) s_hot[d] = 0xffffffffu - d;
+#endif
     uint32_t            seg, begin, end;
     if (!group_range(pp, blockIdx.x, seg, begin, end)) return;
     const uint32_t F = 1u << pp.fanout_log2, mask = F - 1u;
@@ -964,8 +968,12 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_hist(Loader ld, PassParams 
         else
             ok = ld.key_tile(base, end, hk);
 #pragma unroll
-        for (int j = 0; j < PT_ITEMS; ++j)
+        for (int j = 0; j < PT_ITEMS; ++j) {
+#if RJ_PT_HOT_PROBE
+            if (s_hot[(hk[j] >> 9) & 4095u] == hk[j]) ok &= ~(1u << j);
+#endif
             if ((ok >> j) & 1u) atomicAdd(&s_h[pass_digit(pp, hk[j], mask)], 1u);
+        }
     }
     if constexpr (loader_needs_begin<Loader>::value) {
         uint32_t hx;
@@ -1125,6 +1133,12 @@ __global__ __launch_bounds__(PT_MAXF) void k_scan_fine(const uint32_t* fine, uin
 #ifndef RJ_PT_EXTRA_LOOKUP
 #define RJ_PT_EXTRA_LOOKUP 0
 #endif
+// (experiment: the per-tuple cost of a HOT-KEY test — one probe of a 4096-entry LDS set of hashed keys —
+// in the first pass' histogram and scatter, which a skew bypass (hot probe keys joined straight out of the
+// first pass instead of being partitioned twice) would pay for every tuple.  The set is empty here.)
+#ifndef RJ_PT_HOT_PROBE
+#define RJ_PT_HOT_PROBE 0
+#endif
 #ifndef RJ_PT_PIPELINE
 #define RJ_PT_PIPELINE 0
 #endif
@@ -1153,6 +1167,10 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassPara
     __shared__ uint32_t s_base[PT_MAXF];
     __shared__ uint32_t s_delta[PT_MAXF];
     __shared__ uint32_t s_wsum[PT_THREADS / 64];
+#if RJ_PT_HOT_PROBE
+    __shared__ uint32_t s_hot[4096];
+    for (uint32_t d = threadIdx.x; d < 4096; d += PT_THREADS) s_hot[d] = 0xffffffffu - d;
+#endif
     uint32_t            seg, begin, end;
     if (!group_range(pp, blockIdx.x, seg, begin, end)) return;
     const uint32_t F = 1u << pp.fanout_log2, mask = F - 1u;
@@ -1199,6 +1217,9 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassPara
 #pragma unroll
         for (int j = 0; j < PT_ITEMS; ++j) {
             dr[j] = 0xffffffffu;
+#if RJ_PT_HOT_PROBE
+            if (s_hot[(w[j][0] >> 9) & 4095u] == w[j][0]) ok &= ~(1u << j);
+#endif
             if ((ok >> j) & 1u) {
                 uint32_t d = pass_digit(pp, w[j][0], mask);
                 uint32_t r = atomicAdd(&s_cnt[d], 1u);
