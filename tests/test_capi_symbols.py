@@ -119,3 +119,25 @@ def test_every_environment_switch_is_documented():
     doc = open(os.path.join(root, "INTEGRATION.md")).read()
     missing = sorted(n for n in names if n not in doc)
     assert not missing, missing
+
+
+def test_bench_and_smoke_refuse_to_run_without_a_gpu():
+    """bench.py and __graft_entry__.smoke() measure / check the HIP path only: on a box without a GPU
+    they stop with a message instead of timing or checking anything else (skipped where a GPU is present)."""
+    import os
+    import subprocess
+    import sys
+
+    import torch
+
+    if torch.cuda.is_available():
+        import pytest
+
+        pytest.skip("a GPU is present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-extras", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode != 0 and "needs a GPU" in (r.stderr + r.stdout), r.stderr[-500:]
+    assert not any(line.startswith("{") for line in r.stdout.splitlines()), "no result line without a GPU"
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode != 0, "smoke() must fail without a GPU"
