@@ -119,7 +119,7 @@ typedef struct rj_config {
     int32_t  profile;     /* 1: HIP events around the data-moving kernels,
                              2: around every launch; 0: none                   */
     void*    stream;      /* hipStream_t to launch on; NULL = library-owned (single device only) */
-    int32_t  radix_bits;  /* total radix bits; 0 = auto from build cardinality */
+    int32_t  radix_bits;  /* total radix bits; 0 = auto from build cardinality; at most 21 (clamped) */
     int32_t  n_devices;   /* 0 or 1: one device (`device`); N > 1: this context owns devices[0..N) */
     const int32_t* devices;   /* [n_devices] HIP ordinals; an ordinal may repeat (virtual ranks
                                  on one GPU: tests on a single-GPU box)                       */

@@ -16,6 +16,7 @@ static int env_int(const char* name, int def) {
 }
 
 void Tuning::from_env() {
+    blocked_mid = env_int("RJ_TUNE_BLOCKED_MID", blocked_mid);
     mall_chunk = env_int("RJ_TUNE_MALL_CHUNK", mall_chunk);
     radix_bits = env_int("RJ_TUNE_RADIX_BITS", radix_bits);
     p1_bits = env_int("RJ_TUNE_P1_BITS", p1_bits);

@@ -407,10 +407,11 @@ class Exec {
                 continue;
             }
             if ((P.aos3 && passes == 1) || aos_mid) continue;  // every pass writes 12-byte tuples
-            A[a] = ctx->buf(n * wbytes);
+            // (+2048: a blocked array ends with a whole block, see BlockedLoader)
+            A[a] = ctx->buf(n * wbytes + 2048);
             wa.w[a] = A[a]->as<uint32_t>();
             if (passes > (P.aos3 ? 2u : 1u)) {
-                B[a] = ctx->buf(n * wbytes);
+                B[a] = ctx->buf(n * wbytes + 2048);
                 wb.w[a] = B[a]->as<uint32_t>();
             }
         }
@@ -463,6 +464,10 @@ class Exec {
         } chunk_ev;
         const bool chunk_second = ctx->tune.mall_chunk > 0 && passes == 2 && !fine && !shape && !ws && !external && P.packed &&
                                   !packed_side && ctx->tune.xcd_split && n >= (uint64_t)ctx->tune.xcd_min_rows;
+        // RJ_TUNE_BLOCKED_MID: between the passes of a packed plan the pairs lie in blocks of 16 keys + 16 carries
+        // (BlockedLoader), so that the next pass' histogram reads 4 instead of 8 bytes per tuple
+        const bool blocked_mid = ctx->tune.blocked_mid != 0 && P.packed && passes >= 2 && !fine && !shape && !ws && !external &&
+                                 !packed_side && !chunk_second;
         for (uint32_t p = 0; p < passes; ++p) {
             const uint32_t F = 1u << pbits[p];
             PassParams     pp{};
@@ -582,6 +587,8 @@ class Exec {
                         launch_pass_hist_digits(L, SIDE[(p - 1) % 2]->as<uint16_t>(), pp, n_groups);
                     else if (aos_mid && p > 0)
                         launch_pass_hist_aos3(L, MID[(p - 1) % 2]->as<uint32_t>(), pp, n_groups);
+                    else if (P.packed && blocked_mid && p > 0)
+                        launch_pass_hist_blocked(L, cur.w[0], pp, n_groups);
                     else if (P.packed)
                         launch_pass_hist_packed(L, cur.w[0], pp, n_groups);
                     else
@@ -644,8 +651,11 @@ class Exec {
                         pp.next_shift = shift + pbits[p];
                         pp.next_mask = (1u << pbits[p + 1]) - 1u;
                     }
+                    const bool blk_out = blocked_mid && p + 1 < passes;
                     if (p == 0 && !ws)
-                        launch_pass_scatter_src_packed(L, src, pp, n_groups, nxt.w[0]);
+                        launch_pass_scatter_src_packed(L, src, pp, n_groups, nxt.w[0], blk_out);
+                    else if (blocked_mid)
+                        launch_pass_scatter_blocked(L, cur.w[0], pp, n_groups, nxt.w[0], blk_out);
                     else
                         launch_pass_scatter_packed(L, cur.w[0], pp, n_groups, nxt.w[0]);
                 } else if (p == 0 && !ws) {
@@ -885,7 +895,9 @@ class Exec {
             if (js.forced_bits <= 0 && bits > 2 * PT_MAXBITS &&
                 (build_n >> (2 * PT_MAXBITS)) <= (uint64_t)(JN_RMAX * 0.95))
                 bits = 2 * PT_MAXBITS;
-            bits = std::min<uint32_t>(std::max<uint32_t>(bits, 1), 27);
+            // (at most 21: three passes of 7 bits — what 2^32 build rows ask for; more partitions than that
+            // and the join's launch would exceed 2^32 threads.  A larger forced value is clamped.)
+            bits = std::min<uint32_t>(std::max<uint32_t>(bits, 1), 21);
             if (top_bits_taken && bits > 32 - top_bits_taken) bits = 32 - top_bits_taken;
             return bits;
         }

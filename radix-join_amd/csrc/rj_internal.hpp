@@ -169,6 +169,8 @@ struct Result {
 // Tuning / diagnostic knobs, read from the environment ONCE when the context is created (the
 // plan walk is a hot host path: no getenv per join).
 struct Tuning {
+    int blocked_mid = 1;  // RJ_TUNE_BLOCKED_MID: packed pairs between the passes in blocks of 256 keys + 256 carries, so that
+                          // the next pass' histogram reads the keys only (4 instead of 8 bytes per tuple)
     int mall_chunk = 0;   // RJ_TUNE_MALL_CHUNK: segments per chunk of the SECOND pass of packed plans — histogram, scan and
                           // scatter launched chunk by chunk on two streams, so that the scatter re-reads what the
                           // histogram just read from the 256 MiB Infinity Cache instead of HBM (0 = one launch each)

@@ -637,6 +637,49 @@ struct PackedLoader {
     }
 };
 
+// {hashed key, carry} pairs BETWEEN the passes of a packed plan, blocked: tuple g lives in block g / 64 —
+// 128 words: the 64 keys, then the 64 carries — so that the next pass' histogram reads the key halves
+// only (two of every four 128-byte lines: 4 instead of 8 bytes per tuple; with 16-tuple blocks it still
+// pulled every line) while a scatter writes a run of consecutive tuples into ONE array.
+struct BlockedLoader {
+    const uint32_t* in;
+    RJ_TRIVIAL_ISSUE_FINISH
+    __device__ __forceinline__ uint32_t issue_keys(uint32_t base, uint32_t end, uint32_t (&lo)[PT_ITEMS],
+                                                   uint32_t (&)[PT_ITEMS]) const {
+        return key_tile(base, end, lo);
+    }
+    __device__ __forceinline__ uint32_t finish_keys(uint32_t, uint32_t, uint32_t ok, uint32_t (&)[PT_ITEMS],
+                                                    uint32_t (&)[PT_ITEMS]) const {
+        return ok;
+    }
+    static constexpr uint32_t BLK = 256;  // tuples per block: 1 KiB of keys, then 1 KiB of carries (64 / 256 / 1024 measured: profiles/r03_ao_*)
+    static __device__ __forceinline__ size_t key_at(uint32_t g) { return (size_t)(g / BLK) * (2u * BLK) + (g % BLK); }
+    __device__ __forceinline__ uint32_t key_tile(uint32_t base, uint32_t end, uint32_t (&hk)[PT_ITEMS]) const {
+        uint32_t ok = 0;
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS; ++j) {
+            const uint32_t i = base + j * PT_THREADS + threadIdx.x;
+            hk[j] = in[key_at(min(i, end - 1u))];
+            ok |= (uint32_t)(i < end) << j;
+        }
+        return ok;
+    }
+    template <int NW>
+    __device__ __forceinline__ uint32_t load_tile(uint32_t base, uint32_t end, uint32_t (&w)[PT_ITEMS][NW]) const {
+        static_assert(NW == 2, "packed tuples are key + one carry word");
+        uint32_t ok = 0;
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS; ++j) {
+            const uint32_t i = base + j * PT_THREADS + threadIdx.x;
+            const size_t   a = key_at(min(i, end - 1u));
+            w[j][0] = in[a];
+            w[j][1] = in[a + BLK];
+            ok |= (uint32_t)(i < end) << j;
+        }
+        return ok;
+    }
+};
+
 // byte offset of row `row` in a 4-byte / 8-byte column (regular page images or dense)
 __device__ __forceinline__ uint64_t col_off32(bool paged, uint32_t row) {
     uint32_t p = row / ROWS32, i = row - p * ROWS32;
@@ -1372,7 +1415,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter(Loader ld, PassPara
 // halves the number of output streams and doubles the bytes per contiguous run (a run of 64
 // tuples is 512 contiguous bytes instead of two runs of 256), which is what the scatter's
 // rate follows; it also needs one staging round and two barriers less per tile.
-template <class Loader>
+template <class Loader, bool BLK_OUT = false>
 __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter_packed(Loader ld, PassParams pp, uint2* out) {
     __shared__ uint2    s_stage[PT_TILE];
     __shared__ uint32_t s_cnt[PT_MAXF];
@@ -1428,7 +1471,13 @@ __global__ __launch_bounds__(PT_THREADS) void k_pass_scatter_packed(Loader ld, P
             if (i < total) {
                 const uint2    v = s_stage[i];
                 const uint32_t g = s_delta[pass_digit(pp, v.x, mask)] + i;
-                out[g] = v;
+                if constexpr (BLK_OUT) {  // (see BlockedLoader)
+                    uint32_t* o = reinterpret_cast<uint32_t*>(out) + BlockedLoader::key_at(g);
+                    o[0] = v.x;
+                    o[BlockedLoader::BLK] = v.y;
+                } else {
+                    out[g] = v;
+                }
                 if (pp.side_out) pp.side_out[g] = (uint16_t)((v.x >> pp.next_shift) & pp.next_mask);
             }
         }
@@ -2646,11 +2695,32 @@ void launch_pass_hist_packed(const Launch& L, const uint32_t* in_pairs, const Pa
 }
 
 void launch_pass_scatter_src_packed(const Launch& L, const TupleSrc& src, const PassParams& pp,
-                                    uint32_t n_groups, uint32_t* out_pairs) {
+                                    uint32_t n_groups, uint32_t* out_pairs, bool blocked_out) {
     if (!n_groups) return;
     SrcLoader<1, 1> ld{src};
-    RJ_KLAUNCH(L, "pass1_scatter", (k_pass_scatter_packed<SrcLoader<1, 1>>), n_groups, PT_THREADS, ld,
-               pp, reinterpret_cast<uint2*>(out_pairs));
+    if (blocked_out)
+        RJ_KLAUNCH(L, "pass1_scatter", (k_pass_scatter_packed<SrcLoader<1, 1>, true>), n_groups, PT_THREADS, ld,
+                   pp, reinterpret_cast<uint2*>(out_pairs));
+    else
+        RJ_KLAUNCH(L, "pass1_scatter", (k_pass_scatter_packed<SrcLoader<1, 1>>), n_groups, PT_THREADS, ld,
+                   pp, reinterpret_cast<uint2*>(out_pairs));
+}
+
+// a later pass over BLOCKED pairs (see BlockedLoader); its output is blocked again, or — the last pass — packed
+void launch_pass_hist_blocked(const Launch& L, const uint32_t* in_blocked, const PassParams& pp, uint32_t n_groups) {
+    if (!n_groups) return;
+    RJ_KLAUNCH(L, "pass2_hist", (k_pass_hist<BlockedLoader>), n_groups, PT_THREADS, BlockedLoader{in_blocked}, pp);
+}
+void launch_pass_scatter_blocked(const Launch& L, const uint32_t* in_blocked, const PassParams& pp, uint32_t n_groups,
+                                 uint32_t* out_pairs, bool blocked_out) {
+    if (!n_groups) return;
+    BlockedLoader ld{in_blocked};
+    if (blocked_out)
+        RJ_KLAUNCH(L, "pass2_scatter", (k_pass_scatter_packed<BlockedLoader, true>), n_groups, PT_THREADS, ld, pp,
+                   reinterpret_cast<uint2*>(out_pairs));
+    else
+        RJ_KLAUNCH(L, "pass2_scatter", (k_pass_scatter_packed<BlockedLoader>), n_groups, PT_THREADS, ld, pp,
+                   reinterpret_cast<uint2*>(out_pairs));
 }
 
 void launch_pass_scatter_packed(const Launch& L, const uint32_t* in_pairs, const PassParams& pp,

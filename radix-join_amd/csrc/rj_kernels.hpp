@@ -92,7 +92,11 @@ void launch_pass_scatter_aos3(const Launch& L, const uint32_t* in_tuples, const 
 void launch_pass_hist_packed(const Launch& L, const uint32_t* in_pairs, const PassParams& pp,
                              uint32_t n_groups);
 void launch_pass_scatter_src_packed(const Launch& L, const TupleSrc& src, const PassParams& pp,
-                                    uint32_t n_groups, uint32_t* out_pairs);
+                                    uint32_t n_groups, uint32_t* out_pairs, bool blocked_out = false);
+// (pairs between the passes of a packed plan in blocks of 16 keys + 16 carries: the next histogram reads the keys only)
+void launch_pass_hist_blocked(const Launch& L, const uint32_t* in_blocked, const PassParams& pp, uint32_t n_groups);
+void launch_pass_scatter_blocked(const Launch& L, const uint32_t* in_blocked, const PassParams& pp, uint32_t n_groups,
+                                 uint32_t* out_pairs, bool blocked_out);
 void launch_pass_scatter_packed(const Launch& L, const uint32_t* in_pairs, const PassParams& pp,
                                 uint32_t n_groups, uint32_t* out_pairs);
 

@@ -33,6 +33,9 @@ _KNOBS = {
     # the second pass of packed two-pass plans chunk by chunk on two streams (RJ_TUNE_MALL_CHUNK: measured
     # slower at 1 B rows and off by default; 3 segments per chunk here, so that chunks end inside the XCD grid)
     "chunks": ({"RJ_TUNE_XCD_MIN_ROWS": "0", "RJ_TUNE_MALL_CHUNK": "3"}, {"radix_bits": 16}),
+    # packed pairs between the passes as plain 8-byte pairs (RJ_TUNE_BLOCKED_MID=0; the default since round 3
+    # is blocks of 256 keys + 256 carries, which the 16-bit knobs above run through for key + INT32-payload plans)
+    "pairs": ({"RJ_TUNE_XCD_MIN_ROWS": "0", "RJ_TUNE_BLOCKED_MID": "0"}, {"radix_bits": 16}),
 }
 
 
@@ -185,5 +188,42 @@ def test_64_bit_keys_at_14_radix_bits(kt, probe_cols):
         got = capi.execute(p, c)
         assert got.num_rows == want.num_rows and want.num_rows > npr
         assert pl.table_digest(got) == pl.table_digest(want)
+    finally:
+        capi.destroy_context(c)
+
+
+@pytest.mark.parametrize("bits", [16, 20, 21, 27])
+def test_blocked_pairs_between_the_passes(bits):
+    """key + one INT32 payload (packed plan) at forced 16 / 20 / 21 / 27 (clamped to 21) radix bits: two and three
+    plain-histogram passes, the pairs BETWEEN them in blocks of 256 keys + 256 carries (BlockedLoader: the next histogram
+    reads the keys only), the last pass back to 8-byte pairs for the join.  Sizes that end inside a block and
+    inside a tile, NULL keys, duplicates, probe keys that miss; XCD-aware placement forced on."""
+    import os
+
+    rng = np.random.default_rng(5000 + bits)
+    old = os.environ.get("RJ_TUNE_XCD_MIN_ROWS")
+    os.environ["RJ_TUNE_XCD_MIN_ROWS"] = "0"
+    try:
+        c = capi.Context(radix_bits=bits)
+    finally:
+        if old is None:
+            del os.environ["RJ_TUNE_XCD_MIN_ROWS"]
+        else:
+            os.environ["RJ_TUNE_XCD_MIN_ROWS"] = old
+    try:
+        for nb, npr in ((1_000_003, 2_500_001), (70_001, 100), (255, 257)):
+            dom = max(2, int(nb * 0.7))
+            bt = pl.make_table([(pl.INT32, keys(rng, nb, dom, pl.INT32), rng.random(nb) >= 0.03), column(rng, nb, pl.INT32, 0.0)])
+            pt = pl.make_table([(pl.INT32, keys(rng, npr, dom + dom // 4, pl.INT32, hot=0.05), rng.random(npr) >= 0.02), column(rng, npr, pl.INT32, 0.0)])
+            p = pl.Plan()
+            b = p.new_scan_node(0, [(0, pl.INT32), (1, pl.INT32)])
+            s_ = p.new_scan_node(1, [(0, pl.INT32), (1, pl.INT32)])
+            p.root = p.new_join_node(True, b, s_, 0, 0, [(0, pl.INT32), (1, pl.INT32), (3, pl.INT32)])
+            p.new_input(bt)
+            p.new_input(pt)
+            want = _oracle.execute(p)
+            got = capi.execute(p, c)
+            assert got.num_rows == want.num_rows
+            assert pl.table_digest(got) == pl.table_digest(want)
     finally:
         capi.destroy_context(c)
