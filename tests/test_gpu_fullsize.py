@@ -89,8 +89,9 @@ def test_config3_1b_zipf_int64_full_size():
 
 
 def test_uniform_1b_full_size():
-    """1 B ⋈ 1 B INT32 uniform keys, INT32 payloads (2^18 partitions: plain histograms on packed
-    pairs)"""
+    """1 B ⋈ 1 B INT32 uniform keys, INT32 payloads (2^18 partitions of packed 8-byte pairs: two 2^9-way
+    passes with plain histograms, the pairs between them in blocks of 256 keys + 256 carries —
+    BlockedLoader — whose key halves are all the second histogram reads)"""
     run_and_verify("uniform1b")
 
 
